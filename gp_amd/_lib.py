@@ -1,0 +1,308 @@
+"""ctypes binding of libgpmi.so (include/gpmi.h) -- the only way this package computes.
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is
+visible, construction of a Context raises GpmiError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgpmi.so")
+
+KINDS = ("QQ", "QR", "RQ", "RR", "QT", "TQ", "RT", "TR", "TT")
+FULL, LOWER, COMPAT_RR = 0, 1, 2
+
+# every symbol include/gpmi.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "gpmi_version", "gpmi_last_error", "gpmi_device_count", "gpmi_create", "gpmi_destroy",
+    "gpmi_set_stream", "gpmi_sync", "gpmi_reserve", "gpmi_set_option",
+    "gpmi_se_cov", "gpmi_se_cov_dev", "gpmi_deriv_cov", "gpmi_deriv_cov_dev", "gpmi_deriv_elem",
+    "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
+    "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
+    "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
+    "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
+)
+
+
+class GpmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libgpmi error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NotPositiveDefinite(GpmiError):
+    """info = k > 0: the leading minor of order k is not positive definite
+    (base-R chol() error / Stan cholesky_decompose domain_error)."""
+
+    def __init__(self, k):
+        RuntimeError.__init__(self, "the leading minor of order %d is not positive definite" % k)
+        self.code = k
+        self.order = k
+
+
+_lib = None
+
+
+def load():
+    """Load libgpmi.so; loud failure when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpmiError(-4, "%s not found: build it with `python -m gp_amd._build` "
+                        "(hipcc --offload-arch=gfx950); gp_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.gpmi_last_error.restype = C.c_char_p
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name != "gpmi_last_error":
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _chk(rc, allow_info=False):
+    if rc == 0:
+        return 0
+    if rc > 0:
+        if allow_info:
+            return rc
+        raise NotPositiveDefinite(rc)
+    raise GpmiError(rc, load().gpmi_last_error().decode())
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _d(x):
+    return C.c_double(float(x))
+
+
+def _vec(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel())
+
+
+def _mat(X):
+    """2-D column-major float64 view/copy (R's native layout)."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X.reshape(-1, 1)
+    return np.asfortranarray(X)
+
+
+def _kind(k):
+    return KINDS.index(k) if isinstance(k, str) else int(k)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().gpmi_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One gpmi_ctx: bound to one GPU and to this process."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self._lib = load()
+        _chk(self._lib.gpmi_create(C.byref(self._h), int(device)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gpmi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing -----------------------------------------------------------
+    def set_stream(self, stream_handle):
+        _chk(self._lib.gpmi_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def sync(self):
+        _chk(self._lib.gpmi_sync(self._h))
+
+    def reserve(self, n_max):
+        _chk(self._lib.gpmi_reserve(self._h, int(n_max)))
+
+    def set_option(self, name, value):
+        _chk(self._lib.gpmi_set_option(self._h, name.encode(), int(value)))
+
+    def last_timing(self):
+        out = np.zeros(3)
+        _chk(self._lib.gpmi_last_timing(self._h, _p(out)))
+        return out
+
+    def kernel_timing(self, reset=True):
+        """{category: (launches, total_ms, total_work)} for 'build' (bytes) and 'syrk' (flops)."""
+        out = np.zeros(9)
+        _chk(self._lib.gpmi_kernel_timing(self._h, int(bool(reset)), _p(out)))
+        return {"build": tuple(out[0:3]), "syrk": tuple(out[3:6]), "panel": tuple(out[6:9])}
+
+    # ---- covariance builders (host buffers) ----------------------------------
+    def se_cov(self, X, Y, alpha, ell, diag_add=0.0, flags=FULL):
+        X = _mat(X)
+        n, D = X.shape
+        ell = _vec(ell)
+        if Y is None:
+            K = np.empty((n, n), order="F")
+            _chk(self._lib.gpmi_se_cov(self._h, _p(X), n, max(n, 1), None, n, max(n, 1), D, _d(alpha), _p(ell),
+                                       int(ell.size), _d(diag_add), int(flags), _p(K), max(n, 1)))
+            return K
+        Y = _mat(Y)
+        if Y.shape[1] != D:
+            raise GpmiError(-1, "X and Y must have the same number of columns")
+        m = Y.shape[0]
+        K = np.empty((n, m), order="F")
+        _chk(self._lib.gpmi_se_cov(self._h, _p(X), n, max(n, 1), _p(Y), m, max(m, 1), D, _d(alpha), _p(ell),
+                                   int(ell.size), _d(diag_add), int(flags), _p(K), max(n, 1)))
+        return K
+
+    def deriv_cov(self, kind, x, y, alpha, l, flags=FULL):
+        x = _vec(x); y = _vec(y)
+        K = np.empty((x.size, y.size), order="F")
+        _chk(self._lib.gpmi_deriv_cov(self._h, _kind(kind), _p(x), int(x.size), _p(y), int(y.size), _d(alpha),
+                                      _d(l), int(flags), _p(K), max(int(x.size), 1)))
+        return K
+
+    def deriv_elem(self, kind, tj, tk, l):
+        tj, tk = np.broadcast_arrays(np.asarray(tj, dtype=np.float64), np.asarray(tk, dtype=np.float64))
+        shape = tj.shape
+        a = _vec(tj); b = _vec(tk)
+        out = np.empty(a.size)
+        _chk(self._lib.gpmi_deriv_elem(self._h, _kind(kind), _p(a), _p(b), C.c_size_t(a.size), _d(l), _p(out)))
+        return out.reshape(shape)
+
+    def joint_cov(self, t, alpha, l, sigma, jitter=1e-6, flags=FULL):
+        t = _vec(t); n = t.size
+        K = np.empty((2 * n, 2 * n), order="F")
+        _chk(self._lib.gpmi_joint_cov(self._h, _p(t), n, _d(alpha), _d(l), _d(sigma), _d(jitter), int(flags),
+                                      _p(K), max(2 * n, 1)))
+        return K
+
+    # ---- factorisation --------------------------------------------------------
+    def potrf(self, A):
+        """Lower Cholesky factor of A (copy); raises NotPositiveDefinite."""
+        L = np.array(A, dtype=np.float64, order="F", copy=True)
+        n = L.shape[0]
+        if L.ndim != 2 or L.shape[1] != n:
+            raise GpmiError(-1, "matrix must be square")
+        _chk(self._lib.gpmi_potrf(self._h, _p(L), n, max(n, 1)))
+        return L
+
+    def trmv_lower(self, L, z):
+        L = _mat(L); z = _vec(z); f = np.empty_like(z)
+        _chk(self._lib.gpmi_trmv_lower(self._h, _p(L), L.shape[0], max(L.shape[0], 1), _p(z), _p(f)))
+        return f
+
+    def trsv_lower(self, L, b):
+        L = _mat(L); b = _vec(b); z = np.empty_like(b)
+        _chk(self._lib.gpmi_trsv_lower(self._h, _p(L), L.shape[0], max(L.shape[0], 1), _p(b), _p(z)))
+        return z
+
+    # ---- marginal likelihood -------------------------------------------------
+    def logml(self, X, y, alpha, ell, sigma, jitter=0.0):
+        """(logml, sum log L_ii, z'z); raises NotPositiveDefinite."""
+        X = _mat(X); y = _vec(y); ell = _vec(ell)
+        n, D = X.shape
+        if y.size != n:
+            raise GpmiError(-1, "X and y disagree on N")
+        out = np.empty(3)
+        _chk(self._lib.gpmi_logml(self._h, _p(X), n, n, D, _p(y), _d(alpha), _p(ell), int(ell.size), _d(sigma),
+                                  _d(jitter), _p(out)))
+        return out[0], out[1], out[2]
+
+    def logml_grid(self, X, y, alpha, rho, sigma, jitter=0.0):
+        """Arrays (G,3) of (logml, sum log L_ii, z'z) and info (G,) for G hyper-parameter points."""
+        X = _mat(X); y = _vec(y)
+        n, D = X.shape
+        alpha, rho, sigma = np.broadcast_arrays(np.asarray(alpha, float), np.asarray(rho, float), np.asarray(sigma, float))
+        a = _vec(alpha); r = _vec(rho); s = _vec(sigma)
+        G = a.size
+        out = np.empty((G, 3)); info = np.zeros(G, dtype=np.int32)
+        _chk(self._lib.gpmi_logml_grid(self._h, _p(X), n, n, D, _p(y), _p(a), _p(r), _p(s), G, _d(jitter), _p(out),
+                                       _p(info)))
+        return out, info
+
+    def joint_logml(self, t, yy, alpha, l, sigma, jitter=1e-6):
+        t = _vec(t); yy = _vec(yy)
+        if yy.size != 2 * t.size:
+            raise GpmiError(-1, "yy must stack [y; y'] (length 2N)")
+        out = np.empty(3)
+        _chk(self._lib.gpmi_joint_logml(self._h, _p(t), int(t.size), _p(yy), _d(alpha), _d(l), _d(sigma),
+                                        _d(jitter), _p(out)))
+        return out[0], out[1], out[2]
+
+    def rbf_cov_chol(self, x, l):
+        x = _vec(x); n = x.size
+        L = np.empty((n, n), order="F"); dL = np.empty((n, n), order="F")
+        _chk(self._lib.gpmi_rbf_cov_chol(self._h, _p(x), n, _d(l), _p(L), max(n, 1), _p(dL), max(n, 1)))
+        return L, dL
+
+    def gp_condition(self, t, ts, y, alpha, l, s2, jitter, kindK, kindS, kindSS, flags=FULL):
+        t = _vec(t); ts = _vec(ts); y = _vec(y)
+        n, m = t.size, ts.size
+        mn = np.empty(m); Kn = np.empty((m, m), order="F")
+        _chk(self._lib.gpmi_gp_condition(self._h, _p(t), n, _p(ts), m, _p(y), _d(alpha), _d(l), _d(s2), _d(jitter),
+                                         _kind(kindK), _kind(kindS), _kind(kindSS), int(flags), _p(mn), _p(Kn),
+                                         max(m, 1)))
+        return mn, Kn
+
+    # ---- device-pointer API (torch tensors own the memory; plumbing only) -----
+    def logml_dev(self, dX_ptr, n, ldx, D, dy_ptr, alpha, ell, sigma, jitter, dout_ptr, dinfo_ptr):
+        ell = _vec(ell)
+        _chk(self._lib.gpmi_logml_dev(self._h, C.c_void_p(dX_ptr), int(n), int(ldx), int(D), C.c_void_p(dy_ptr),
+                                      _d(alpha), _p(ell), int(ell.size), _d(sigma), _d(jitter),
+                                      C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
+
+    def logml_grid_dev(self, dX_ptr, n, ldx, D, dy_ptr, alpha, rho, sigma, jitter, dout_ptr, dinfo_ptr):
+        a = _vec(alpha); r = _vec(rho); s = _vec(sigma)
+        _chk(self._lib.gpmi_logml_grid_dev(self._h, C.c_void_p(dX_ptr), int(n), int(ldx), int(D),
+                                           C.c_void_p(dy_ptr), _p(a), _p(r), _p(s), int(a.size), _d(jitter),
+                                           C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
+
+    def joint_logml_dev(self, dt_ptr, n, dyy_ptr, alpha, l, sigma, jitter, dout_ptr, dinfo_ptr):
+        _chk(self._lib.gpmi_joint_logml_dev(self._h, C.c_void_p(dt_ptr), int(n), C.c_void_p(dyy_ptr), _d(alpha),
+                                            _d(l), _d(sigma), _d(jitter), C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
+
+    def se_cov_dev(self, dX_ptr, n, ldx, dY_ptr, m, ldy, D, alpha, ell, diag_add, flags, dK_ptr, ldk):
+        ell = _vec(ell)
+        _chk(self._lib.gpmi_se_cov_dev(self._h, C.c_void_p(dX_ptr), int(n), int(ldx),
+                                       C.c_void_p(dY_ptr) if dY_ptr else None, int(m), int(ldy), int(D), _d(alpha),
+                                       _p(ell), int(ell.size), _d(diag_add), int(flags), C.c_void_p(dK_ptr), int(ldk)))
+
+    def potrf_dev(self, dA_ptr, n, lda, dinfo_ptr):
+        _chk(self._lib.gpmi_potrf_dev(self._h, C.c_void_p(dA_ptr), int(n), int(lda), C.c_void_p(dinfo_ptr)))
+
+    # ---- diagnostics ----------------------------------------------------------
+    def probe_mfma(self, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+        out = np.empty((16, 16))
+        _chk(self._lib.gpmi_probe_mfma(self._h, _p(A), _p(B), _p(out)))
+        return out
+
+    def probe_mfma_peak(self, iters=20000):
+        t = C.c_double(0.0)
+        _chk(self._lib.gpmi_probe_mfma_peak(self._h, int(iters), C.byref(t)))
+        return t.value
+
+
+_default = {}
+
+
+def default_context(device=None):
+    """Process-wide lazily created context (one per device); re-created after fork."""
+    if device is None:
+        device = int(os.environ.get("GPMI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    key = (os.getpid(), device)
+    if key not in _default:
+        _default[key] = Context(device)
+    return _default[key]

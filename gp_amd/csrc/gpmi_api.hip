@@ -1,0 +1,806 @@
+// C-ABI implementation of libgpmi (include/gpmi.h).  Host-side orchestration only:
+// every arithmetic operation on matrix data runs in a HIP kernel on the context's
+// stream.  There is no CPU fallback path.
+#include "gpmi_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+int gpmi_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *gpmi_last_error(void) { return g_err; }
+extern "C" int gpmi_version(void) { return GPMI_VERSION; }
+
+extern "C" int gpmi_device_count(int *count)
+{
+    if (!count) return gpmi_fail(GPMI_EARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return gpmi_fail(GPMI_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return 0;
+}
+
+// ---- per-kernel event timing --------------------------------------------------
+struct KTimer {
+    std::vector<hipEvent_t> a[3], b[3];
+    size_t used[3] = {0, 0, 0};
+    double work[3] = {0, 0, 0};
+};
+
+void kt_begin(gpmi_ctx *c, int cat)
+{
+    if (!c->ktiming) return;
+    KTimer *k = (KTimer *)c->ktimer;
+    if (k->used[cat] == k->a[cat].size()) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        k->a[cat].push_back(e0);
+        k->b[cat].push_back(e1);
+    }
+    hipEventRecord(k->a[cat][k->used[cat]], c->stream);
+}
+
+void kt_end(gpmi_ctx *c, int cat, double work)
+{
+    if (!c->ktiming) return;
+    KTimer *k = (KTimer *)c->ktimer;
+    hipEventRecord(k->b[cat][k->used[cat]], c->stream);
+    k->used[cat]++;
+    k->work[cat] += work;
+}
+
+extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9);
+
+// ---- context ---------------------------------------------------------------
+static int enter(gpmi_ctx *c)
+{
+    if (!c) return gpmi_fail(GPMI_EARG, "ctx is NULL");
+    if (c->pid != (int)getpid())
+        return gpmi_fail(GPMI_EFORK, "gpmi context used from a forked child (pid %d, created in %d); "
+                                     "create one context per process", (int)getpid(), c->pid);
+    HIPCHK(hipSetDevice(c->device));
+    return 0;
+}
+#define ENTER(c)                 \
+    do {                         \
+        int rc_ = enter(c);      \
+        if (rc_) return rc_;     \
+    } while (0)
+
+extern "C" int gpmi_create(gpmi_ctx **out, int device)
+{
+    if (!out) return gpmi_fail(GPMI_EARG, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return gpmi_fail(GPMI_ENODEV, "no HIP device visible (libgpmi has no CPU fallback)");
+    if (device < 0 || device >= n) return gpmi_fail(GPMI_EARG, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return gpmi_fail(GPMI_ENODEV, "device %d is %s; libgpmi is built for gfx950 only", device, prop.gcnArchName);
+    gpmi_ctx *c = (gpmi_ctx *)calloc(1, sizeof(gpmi_ctx));
+    if (!c) return gpmi_fail(GPMI_ENOMEM, "host allocation failed");
+    c->device = device;
+    c->pid = (int)getpid();
+    c->nb_outer = 256;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipMalloc((void **)&c->Fpack, GPMI_FPACK * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&c->d_info, 64));
+    HIPCHK(hipMalloc((void **)&c->d_out, 64));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    *out = c;
+    return 0;
+}
+
+extern "C" int gpmi_destroy(gpmi_ctx *c)
+{
+    if (!c) return 0;
+    if (c->pid == (int)getpid()) {
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+        hipFree(c->W);
+        hipFree(c->Fpack);
+        hipFree(c->d_info);
+        hipFree(c->d_out);
+        hipFree(c->scratch);
+        for (int i = 0; i < 4; ++i) {
+            hipFree(c->stage[i]);
+            hipEventDestroy(c->ev[i]);
+        }
+        hipStreamDestroy(c->own_stream);
+    }
+    free(c);
+    return 0;
+}
+
+extern "C" int gpmi_set_stream(gpmi_ctx *c, void *hip_stream)
+{
+    ENTER(c);
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+extern "C" int gpmi_sync(gpmi_ctx *c)
+{
+    ENTER(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
+{
+    ENTER(c);
+    if (!name) return gpmi_fail(GPMI_EARG, "option name is NULL");
+    if (!strcmp(name, "nb_outer")) {
+        if (value == 0) value = 256;
+        if (value < GPMI_NB || value % GPMI_NB) return gpmi_fail(GPMI_EARG, "nb_outer must be a multiple of %d", GPMI_NB);
+        c->nb_outer = value;
+        return 0;
+    }
+    if (!strcmp(name, "timing")) {
+        c->timing = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "kernel_timing")) {
+        if (!c->ktimer) c->ktimer = new KTimer();
+        c->ktiming = value != 0;
+        return 0;
+    }
+    return gpmi_fail(GPMI_EARG, "unknown option '%s'", name);
+}
+
+// workspace for an (rows x cols) lower-stored matrix; ld padded so that columns do not
+// alias HBM channels and 16-column slack exists past the end for tile over-reads
+static int reserve_ws(gpmi_ctx *c, int rows, int cols)
+{
+    const int ld = ((rows + 15) / 16) * 16 + 16;
+    const size_t need = ((size_t)ld * (size_t)(cols + 1) + 4096) * sizeof(double);
+    if (need > c->W_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->W) HIPCHK(hipFree(c->W));
+        c->W = nullptr;
+        c->W_bytes = 0;
+        if (hipMalloc((void **)&c->W, need) != hipSuccess)
+            return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of workspace", need);
+        c->W_bytes = need;
+    }
+    c->ld = ld;
+    c->ncols = cols;
+    return 0;
+}
+
+extern "C" int gpmi_reserve(gpmi_ctx *c, int n_max)
+{
+    ENTER(c);
+    if (n_max <= 0) return gpmi_fail(GPMI_EARG, "n_max must be positive");
+    return reserve_ws(c, n_max + 1, n_max + 1);
+}
+
+static int stage_buf(gpmi_ctx *c, int slot, size_t bytes, double **out)
+{
+    bytes += 4096 * sizeof(double);  // slack for tile over-reads
+    if (bytes > c->stage_bytes[slot]) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->stage[slot]) HIPCHK(hipFree(c->stage[slot]));
+        c->stage[slot] = nullptr;
+        c->stage_bytes[slot] = 0;
+        if (hipMalloc((void **)&c->stage[slot], bytes) != hipSuccess)
+            return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of staging", bytes);
+        c->stage_bytes[slot] = bytes;
+    }
+    *out = c->stage[slot];
+    return 0;
+}
+
+static int scratch_buf(gpmi_ctx *c, size_t bytes, double **out)
+{
+    if (bytes > c->scratch_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->scratch) HIPCHK(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+        if (hipMalloc((void **)&c->scratch, bytes) != hipSuccess)
+            return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of scratch", bytes);
+        c->scratch_bytes = bytes;
+    }
+    *out = c->scratch;
+    return 0;
+}
+
+static int fill_params(SeParams *p, int D, double alpha, const double *ell, int n_ell)
+{
+    if (D < 1 || D > GPMI_MAXD) return gpmi_fail(GPMI_EARG, "D = %d unsupported (1..%d)", D, GPMI_MAXD);
+    if (!ell || (n_ell != 1 && n_ell != D)) return gpmi_fail(GPMI_EARG, "length-scale vector must have length 1 or D");
+    p->a2 = alpha * alpha;
+    p->D = D;
+    for (int d = 0; d < GPMI_MAXD; ++d) p->inv_ell[d] = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double l = ell[n_ell == 1 ? 0 : d];
+        if (!(l > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
+        p->inv_ell[d] = 1.0 / l;
+    }
+    return 0;
+}
+
+// copy a host column-major block (rows x cols, ld) to a packed device buffer (ld = rows)
+static int h2d_matrix(gpmi_ctx *c, const double *h, int rows, int cols, int ldh, double *d)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    HIPCHK(hipMemcpy2DAsync(d, (size_t)rows * sizeof(double), h, (size_t)ldh * sizeof(double),
+                            (size_t)rows * sizeof(double), cols, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+static int d2h_matrix(gpmi_ctx *c, const double *d, size_t ldd, int rows, int cols, double *h, int ldh)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    HIPCHK(hipMemcpy2DAsync(h, (size_t)ldh * sizeof(double), d, ldd * sizeof(double),
+                            (size_t)rows * sizeof(double), cols, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+// ---- covariance builders ------------------------------------------------------
+extern "C" int gpmi_se_cov_dev(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dY, int m,
+                               int ldy, int D, double alpha, const double *ell, int n_ell,
+                               double diag_add, int flags, double *dK, int ldk)
+{
+    ENTER(c);
+    if (n < 0 || m < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (!dY) m = n;
+    if (n == 0 || m == 0) return 0;
+    if (!dX || !dK || ldx < n || ldk < n || (dY && ldy < m)) return gpmi_fail(GPMI_EARG, "bad pointer or leading dimension");
+    if ((flags & GPMI_LOWER) && dY) return gpmi_fail(GPMI_EARG, "GPMI_LOWER needs Y == NULL (symmetric case)");
+    SeParams p;
+    int rc = fill_params(&p, D, alpha, ell, n_ell);
+    if (rc) return rc;
+    launch_se_cov(c->stream, dX, n, ldx, dY, m, ldy, p, diag_add, (flags & GPMI_LOWER) ? 1 : 0, dK, (size_t)ldk);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_se_cov(gpmi_ctx *c, const double *X, int n, int ldx, const double *Y, int m, int ldy,
+                           int D, double alpha, const double *ell, int n_ell, double diag_add, int flags,
+                           double *K, int ldk)
+{
+    ENTER(c);
+    if (n < 0 || m < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (!Y) m = n;
+    if (n == 0 || m == 0) return 0;
+    if (!X || !K || ldx < n || ldk < n || (Y && ldy < m) || D < 1) return gpmi_fail(GPMI_EARG, "bad pointer or leading dimension");
+    double *dX, *dY = nullptr, *dK;
+    int rc;
+    if ((rc = stage_buf(c, 0, (size_t)n * D * sizeof(double), &dX))) return rc;
+    if (Y && (rc = stage_buf(c, 1, (size_t)m * D * sizeof(double), &dY))) return rc;
+    const int ldd = (n + 1) & ~1;
+    if ((rc = stage_buf(c, 2, (size_t)ldd * m * sizeof(double), &dK))) return rc;
+    if ((rc = h2d_matrix(c, X, n, D, ldx, dX))) return rc;
+    if (Y && (rc = h2d_matrix(c, Y, m, D, ldy, dY))) return rc;
+    if (flags & GPMI_LOWER) HIPCHK(hipMemsetAsync(dK, 0, (size_t)ldd * m * sizeof(double), c->stream));
+    if ((rc = gpmi_se_cov_dev(c, dX, n, n, dY, m, m, D, alpha, ell, n_ell, diag_add, flags, dK, ldd))) return rc;
+    if ((rc = d2h_matrix(c, dK, ldd, n, m, K, ldk))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_deriv_cov_dev(gpmi_ctx *c, int kind, const double *dx, int n, const double *dy, int m,
+                                  double alpha, double l, int flags, double *dK, int ldk)
+{
+    ENTER(c);
+    if (kind < 0 || kind > GPMI_TT) return gpmi_fail(GPMI_EARG, "bad kernel kind %d", kind);
+    if (n < 0 || m < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (n == 0 || m == 0) return 0;
+    if (!dx || !dy || !dK || ldk < n || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    launch_deriv_cov(c->stream, kind, dx, n, dy, m, alpha * alpha, l, (flags & GPMI_COMPAT_RR) ? 1 : 0,
+                     (flags & GPMI_LOWER) ? 1 : 0, dK, (size_t)ldk);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_deriv_cov(gpmi_ctx *c, int kind, const double *x, int n, const double *y, int m,
+                              double alpha, double l, int flags, double *K, int ldk)
+{
+    ENTER(c);
+    if (n < 0 || m < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (n == 0 || m == 0) return 0;
+    if (!x || !y || !K || ldk < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dx, *dy, *dK;
+    int rc;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)m * sizeof(double), &dy))) return rc;
+    const int ldd = (n + 1) & ~1;
+    if ((rc = stage_buf(c, 2, (size_t)ldd * m * sizeof(double), &dK))) return rc;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dy, y, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (flags & GPMI_LOWER) HIPCHK(hipMemsetAsync(dK, 0, (size_t)ldd * m * sizeof(double), c->stream));
+    if ((rc = gpmi_deriv_cov_dev(c, kind, dx, n, dy, m, alpha, l, flags, dK, ldd))) return rc;
+    if ((rc = d2h_matrix(c, dK, ldd, n, m, K, ldk))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_deriv_elem(gpmi_ctx *c, int kind, const double *tj, const double *tk, size_t len,
+                               double l, double *out)
+{
+    ENTER(c);
+    if (kind < 0 || kind > GPMI_TT) return gpmi_fail(GPMI_EARG, "bad kernel kind %d", kind);
+    if (len == 0) return 0;
+    if (!tj || !tk || !out || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *a, *b, *o;
+    int rc;
+    if ((rc = stage_buf(c, 0, len * sizeof(double), &a))) return rc;
+    if ((rc = stage_buf(c, 1, len * sizeof(double), &b))) return rc;
+    if ((rc = stage_buf(c, 2, len * sizeof(double), &o))) return rc;
+    HIPCHK(hipMemcpyAsync(a, tj, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b, tk, len * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_deriv_elem(c->stream, kind, a, b, len, l, o);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, o, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_joint_cov(gpmi_ctx *c, const double *t, int n, double alpha, double l, double sigma,
+                              double jitter, int flags, double *K, int ldk)
+{
+    ENTER(c);
+    if (n < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (n == 0) return 0;
+    if (!t || !K || ldk < 2 * n || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dt, *dK;
+    int rc;
+    const int n2 = 2 * n;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dt))) return rc;
+    if ((rc = stage_buf(c, 2, (size_t)n2 * n2 * sizeof(double), &dK))) return rc;
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (flags & GPMI_LOWER) HIPCHK(hipMemsetAsync(dK, 0, (size_t)n2 * n2 * sizeof(double), c->stream));
+    launch_joint_cov(c->stream, dt, n, alpha * alpha, l, sigma * sigma, jitter, (flags & GPMI_COMPAT_RR) ? 1 : 0,
+                     (flags & GPMI_LOWER) ? 1 : 0, dK, (size_t)n2);
+    HIPCHK(hipGetLastError());
+    if ((rc = d2h_matrix(c, dK, n2, n2, n2, K, ldk))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- factorisation ------------------------------------------------------------
+static void tic(gpmi_ctx *c, int i)
+{
+    if (c->timing) hipEventRecord(c->ev[i], c->stream);
+}
+
+extern "C" int gpmi_potrf_dev(gpmi_ctx *c, double *dA, int n, int lda, int *d_info)
+{
+    ENTER(c);
+    if (n < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (!d_info) return gpmi_fail(GPMI_EARG, "d_info is NULL");
+    HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), c->stream));
+    if (n == 0) return 0;
+    if (!dA || lda < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    if ((rc = reserve_ws(c, n, n))) return rc;
+    launch_copy_matrix(c->stream, dA, (size_t)lda, c->W, (size_t)c->ld, n, n, 1);
+    if ((rc = launch_potrf_partial(c, c->W, (size_t)c->ld, n, n, n, d_info, nullptr))) return rc;
+    launch_copy_matrix(c->stream, c->W, (size_t)c->ld, dA, (size_t)lda, n, n, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_potrf(gpmi_ctx *c, double *A, int n, int lda)
+{
+    ENTER(c);
+    if (n < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (n == 0) return 0;
+    if (!A || lda < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dA;
+    int rc;
+    if ((rc = stage_buf(c, 2, (size_t)n * n * sizeof(double), &dA))) return rc;
+    if ((rc = h2d_matrix(c, A, n, n, lda, dA))) return rc;
+    if ((rc = gpmi_potrf_dev(c, dA, n, n, c->d_info))) return rc;
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_matrix(c, dA, n, n, n, A, lda))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return info;
+}
+
+extern "C" int gpmi_trmv_lower(gpmi_ctx *c, const double *L, int n, int ldl, const double *z, double *f)
+{
+    ENTER(c);
+    if (n < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (n == 0) return 0;
+    if (!L || !z || !f || ldl < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dL, *dz, *df;
+    int rc;
+    if ((rc = stage_buf(c, 2, (size_t)n * n * sizeof(double), &dL))) return rc;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dz))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)n * sizeof(double), &df))) return rc;
+    if ((rc = h2d_matrix(c, L, n, n, ldl, dL))) return rc;
+    HIPCHK(hipMemcpyAsync(dz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_trmv_lower(c->stream, dL, (size_t)n, n, dz, df);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(f, df, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// z = L^-1 b for a given lower factor (mdivide_left_tri_low): z^T = b^T L^-T as a one-row
+// right-solve with the panel kernels; the block factors are packed from L itself.
+extern "C" int gpmi_trsv_lower(gpmi_ctx *c, const double *L, int n, int ldl, const double *b, double *z)
+{
+    ENTER(c);
+    if (n < 0) return gpmi_fail(GPMI_EARG, "negative size");
+    if (n == 0) return 0;
+    if (!L || !b || !z || ldl < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    const int ldd = ((n + 15) / 16) * 16 + 16;
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    double *dL, *db, *dx, *Fall;
+    if ((rc = stage_buf(c, 2, (size_t)ldd * (n + 1) * sizeof(double), &dL))) return rc;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &db))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)2 * (n + 1) * sizeof(double), &dx))) return rc;
+    if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpy2DAsync(dL, (size_t)ldd * sizeof(double), L, (size_t)ldl * sizeof(double),
+                            (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(db, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_set_row(s, dx, 2, 0, db, n, n);  // 1 x n row vector stored with ld = 2 (16-B aligned columns)
+    launch_pack_factors(s, dL, (size_t)ldd, n, Fall);
+    if ((rc = launch_trsm_right(c, dL, (size_t)ldd, n, dx, 2, 1, Fall))) return rc;
+    launch_get_row(s, dx, 2, 0, 0, n, 1.0, db);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(z, db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- marginal likelihood -----------------------------------------------------
+static int logml_core(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dy, const SeParams &p,
+                      double diag_add, double *d_out3, int *d_info)
+{
+    int rc;
+    const int M = n + 1;
+    if ((rc = reserve_ws(c, M, n))) return rc;
+    const size_t ld = (size_t)c->ld;
+    tic(c, 0);
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+    kt_begin(c, 0);
+    launch_se_cov(c->stream, dX, n, ldx, nullptr, n, ldx, p, diag_add, 1, c->W, ld);
+    kt_end(c, 0, 4.0 * (double)n * ((double)n + 1.0));  // lower triangle incl. diagonal, 8 B each
+    launch_set_row(c->stream, c->W, ld, n, dy, n, n);
+    tic(c, 1);
+    if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, nullptr))) return rc;
+    tic(c, 2);
+    launch_logml_finalize(c->stream, c->W, ld, n, n, c->d_info, d_out3, d_info);
+    tic(c, 3);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_logml_dev(gpmi_ctx *c, const double *dX, int n, int ldx, int D, const double *dy,
+                              double alpha, const double *ell, int n_ell, double sigma, double jitter,
+                              double *d_out3, int *d_info)
+{
+    ENTER(c);
+    if (n <= 0 || !dX || !dy || !d_out3 || ldx < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    SeParams p;
+    int rc = fill_params(&p, D, alpha, ell, n_ell);
+    if (rc) return rc;
+    return logml_core(c, dX, n, ldx, dy, p, sigma * sigma + jitter, d_out3, d_info);
+}
+
+extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx, int D, const double *dy,
+                                   const double *alpha, const double *rho, const double *sigma, int G,
+                                   double jitter, double *d_out3, int *d_info)
+{
+    ENTER(c);
+    if (G < 0) return gpmi_fail(GPMI_EARG, "negative grid size");
+    if (G == 0) return 0;
+    if (n <= 0 || !dX || !dy || !alpha || !rho || !sigma || !d_out3 || !d_info || ldx < n)
+        return gpmi_fail(GPMI_EARG, "bad argument");
+    for (int g = 0; g < G; ++g) {
+        SeParams p;
+        int rc = fill_params(&p, D, alpha[g], &rho[g], 1);
+        if (rc) return rc;
+        if ((rc = logml_core(c, dX, n, ldx, dy, p, sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g)))
+            return rc;
+    }
+    return 0;
+}
+
+static int upload_xy(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y, double **dX, double **dy)
+{
+    int rc;
+    if ((rc = stage_buf(c, 0, (size_t)n * D * sizeof(double), dX))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)n * sizeof(double), dy))) return rc;
+    if ((rc = h2d_matrix(c, X, n, D, ldx, *dX))) return rc;
+    HIPCHK(hipMemcpyAsync(*dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_logml(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
+                          double alpha, const double *ell, int n_ell, double sigma, double jitter, double *out3)
+{
+    ENTER(c);
+    if (n <= 0 || !X || !y || !out3 || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dX, *dy;
+    int rc;
+    if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
+    if ((rc = gpmi_logml_dev(c, dX, n, n, D, dy, alpha, ell, n_ell, sigma, jitter, c->d_out, c->d_info + 1))) return rc;
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(out3, c->d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&info, c->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->timing) {
+        float ms;
+        for (int i = 0; i < 3; ++i) {
+            hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+            c->last_ms[i] = ms;
+        }
+    }
+    return info;
+}
+
+extern "C" int gpmi_logml_grid(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
+                               const double *alpha, const double *rho, const double *sigma, int G,
+                               double jitter, double *out3, int *info)
+{
+    ENTER(c);
+    if (G < 0) return gpmi_fail(GPMI_EARG, "negative grid size");
+    if (G == 0) return 0;
+    if (n <= 0 || !X || !y || !out3 || !info || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dX, *dy, *dres;
+    int rc;
+    if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
+    if ((rc = scratch_buf(c, (size_t)G * (3 * sizeof(double) + sizeof(int)) + 64, &dres))) return rc;
+    int *dinfo = (int *)(dres + 3 * (size_t)G);
+    if ((rc = gpmi_logml_grid_dev(c, dX, n, n, D, dy, alpha, rho, sigma, G, jitter, dres, dinfo))) return rc;
+    HIPCHK(hipMemcpyAsync(out3, dres, (size_t)G * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_joint_logml_dev(gpmi_ctx *c, const double *dt, int n, const double *dyy, double alpha,
+                                    double l, double sigma, double jitter, double *d_out3, int *d_info)
+{
+    ENTER(c);
+    if (n <= 0 || !dt || !dyy || !d_out3 || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    const int n2 = 2 * n, M = n2 + 1;
+    if ((rc = reserve_ws(c, M, n2))) return rc;
+    const size_t ld = (size_t)c->ld;
+    tic(c, 0);
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
+    kt_begin(c, 0);
+    launch_joint_cov(c->stream, dt, n, alpha * alpha, l, sigma * sigma, jitter, 0, 1, c->W, ld);
+    kt_end(c, 0, 4.0 * (double)n2 * ((double)n2 + 1.0));
+    launch_set_row(c->stream, c->W, ld, n2, dyy, n2, n2);
+    tic(c, 1);
+    if ((rc = launch_potrf_partial(c, c->W, ld, M, n2, n2, c->d_info, nullptr))) return rc;
+    tic(c, 2);
+    launch_logml_finalize(c->stream, c->W, ld, n2, n2, c->d_info, d_out3, d_info);
+    tic(c, 3);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_joint_logml(gpmi_ctx *c, const double *t, int n, const double *yy, double alpha,
+                                double l, double sigma, double jitter, double *out3)
+{
+    ENTER(c);
+    if (n <= 0 || !t || !yy || !out3) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dt, *dyy;
+    int rc;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dt))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)2 * n * sizeof(double), &dyy))) return rc;
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dyy, yy, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = gpmi_joint_logml_dev(c, dt, n, dyy, alpha, l, sigma, jitter, c->d_out, c->d_info + 1))) return rc;
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(out3, c->d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&info, c->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return info;
+}
+
+// ---- rbf_cov_chol (covariance.cpp:9-47) ---------------------------------------
+__global__ void k_rbf_dsigma(const double *__restrict__ x, int n, double l, double *__restrict__ S, size_t ld)
+{
+    // dSigma/dl = Sigma * (xi-xj)^2 / l^3  (tangent of covariance.cpp:19 with dl = 1, :13)
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= n) return;
+    const double xi = x[i];
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j >= n) break;
+        const double r = xi - x[j], r2 = r * r;
+        S[(size_t)i + (size_t)j * ld] = exp(-r2 / (2 * l * l)) * r2 / (l * l * l);
+    }
+}
+
+extern "C" int gpmi_rbf_cov_chol(gpmi_ctx *c, const double *x, int n, double l, double *L, int ldl,
+                                 double *dLdl, int lddl)
+{
+    ENTER(c);
+    if (n <= 0 || !x || !L || !dLdl || ldl < n || lddl < n || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    if ((rc = reserve_ws(c, n, n))) return rc;
+    const size_t ld = (size_t)c->ld;
+    const int ldd = ((n + 15) / 16) * 16 + 16;
+    const size_t msz = (size_t)ldd * (n + 1) * sizeof(double);
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    double *dx, *S, *S2, *Lc, *Fall;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
+    if ((rc = stage_buf(c, 1, msz, &S))) return rc;
+    if ((rc = stage_buf(c, 2, msz, &S2))) return rc;
+    if ((rc = stage_buf(c, 3, msz, &Lc))) return rc;
+    if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    // Sigma (+1e-10 jitter, covariance.cpp:23-25) -> L
+    SeParams p;
+    double ell = l;
+    if ((rc = fill_params(&p, 1, 1.0, &ell, 1))) return rc;
+    launch_se_cov(s, dx, n, n, nullptr, n, n, p, 1e-10, 1, c->W, ld);
+    if ((rc = launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, Fall))) return rc;
+    launch_copy_matrix(s, c->W, ld, Lc, (size_t)ldd, n, n, 1);
+    // tangent: Ldot = L Phi(L^-1 Sdot L^-T), Phi = lower triangle with halved diagonal
+    hipLaunchKernelGGL(k_rbf_dsigma, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, dx, n, l, S, (size_t)ldd);
+    if ((rc = launch_trsm_right(c, Lc, (size_t)ldd, n, S, (size_t)ldd, n, Fall))) return rc;     // S <- Sdot L^-T
+    launch_transpose(s, S, (size_t)ldd, S2, (size_t)ldd, n, n);                                  // S2 = L^-1 Sdot
+    if ((rc = launch_trsm_right(c, Lc, (size_t)ldd, n, S2, (size_t)ldd, n, Fall))) return rc;    // S2 <- L^-1 Sdot L^-T
+    launch_phi_mask(s, S2, (size_t)ldd, n);                                                       // Phi^T (upper)
+    launch_gemm_nt(s, Lc, (size_t)ldd, S2, (size_t)ldd, S, (size_t)ldd, n, n, n, 0);              // S = L Phi
+    HIPCHK(hipGetLastError());
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if ((rc = d2h_matrix(c, Lc, (size_t)ldd, n, n, L, ldl))) return rc;
+    if ((rc = d2h_matrix(c, S, (size_t)ldd, n, n, dLdl, lddl))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    return info;
+}
+
+// ---- GP posterior ---------------------------------------------------------------
+extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const double *ts, int m,
+                                 const double *y, double alpha, double l, double s2, double jitter,
+                                 int kindK, int kindS, int kindSS, int flags, double *mn, double *Kn, int ldkn)
+{
+    ENTER(c);
+    if (n <= 0 || m <= 0 || !t || !ts || !y || !mn || !Kn || ldkn < m || !(l > 0.0))
+        return gpmi_fail(GPMI_EARG, "bad argument");
+    if (kindK < 0 || kindK > GPMI_TT || kindS < 0 || kindS > GPMI_TT || kindSS < 0 || kindSS > GPMI_TT)
+        return gpmi_fail(GPMI_EARG, "bad kernel kind");
+    int rc;
+    const int nt = n + m, M = nt + 1;
+    if ((rc = reserve_ws(c, M, nt))) return rc;
+    const size_t ld = (size_t)c->ld;
+    double *dt, *dts, *dy, *dKn;
+    if ((rc = stage_buf(c, 0, (size_t)(n + m) * sizeof(double), &dt))) return rc;
+    dts = dt + n;
+    if ((rc = stage_buf(c, 1, (size_t)n * sizeof(double), &dy))) return rc;
+    const int ldo = (m + 1) & ~1;
+    if ((rc = stage_buf(c, 2, (size_t)ldo * (m + 1) * sizeof(double), &dKn))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dts, ts, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    const double a2 = alpha * alpha;
+    const int compat = (flags & GPMI_COMPAT_RR) ? 1 : 0;
+    // [[K + s2 I, .], [Ks, Kss]] lower-stored, then the row [y^T, 0]
+    launch_deriv_cov(s, kindK, dt, n, dt, n, a2, l, compat, 1, c->W, ld);
+    launch_add_diag(s, c->W, ld, n, s2);
+    launch_deriv_cov(s, kindS, dts, m, dt, n, a2, l, compat, 0, c->W + n, ld);
+    launch_deriv_cov(s, kindSS, dts, m, dts, m, a2, l, compat, 1, c->W + n + (size_t)n * ld, ld);
+    launch_set_row(s, c->W, ld, nt, dy, n, nt);
+    // factor the first n columns: rows n.. become Ks L^-T, the trailing block the Schur
+    // complement Kss - Ks (K+s2 I)^-1 Ks^T, the last row [z^T, -mn^T]
+    if ((rc = launch_potrf_partial(c, c->W, ld, M, nt, n, c->d_info, nullptr))) return rc;
+    launch_copy_matrix(s, c->W + n + (size_t)n * ld, ld, dKn, (size_t)ldo, m, m, 2);
+    launch_add_diag(s, dKn, (size_t)ldo, m, jitter);
+    double *dmn = dKn + (size_t)ldo * m;  // spare column of the output staging
+    launch_get_row(s, c->W, ld, nt, n, m, -1.0, dmn);
+    HIPCHK(hipGetLastError());
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if ((rc = d2h_matrix(c, dKn, (size_t)ldo, m, m, Kn, ldkn))) return rc;
+    HIPCHK(hipMemcpyAsync(mn, dmn, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return info;
+}
+
+// ---- diagnostics ---------------------------------------------------------------
+extern "C" int gpmi_last_timing(gpmi_ctx *c, double *ms3)
+{
+    ENTER(c);
+    if (!ms3) return gpmi_fail(GPMI_EARG, "ms3 is NULL");
+    for (int i = 0; i < 3; ++i) ms3[i] = c->last_ms[i];
+    return 0;
+}
+
+// out9[3*cat + 0..2] = launches, total ms, total work (bytes for cat 0, flops for 1 and 2) since
+// the last reset; synchronises the stream.
+extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
+{
+    ENTER(c);
+    if (!c->ktimer) return gpmi_fail(GPMI_EARG, "kernel timing was never enabled");
+    KTimer *k = (KTimer *)c->ktimer;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (out9) {
+        for (int cat = 0; cat < 3; ++cat) {
+            double tot = 0.0;
+            for (size_t i = 0; i < k->used[cat]; ++i) {
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, k->a[cat][i], k->b[cat][i]));
+                tot += ms;
+            }
+            out9[3 * cat] = (double)k->used[cat];
+            out9[3 * cat + 1] = tot;
+            out9[3 * cat + 2] = k->work[cat];
+        }
+    }
+    if (reset)
+        for (int cat = 0; cat < 3; ++cat) {
+            k->used[cat] = 0;
+            k->work[cat] = 0.0;
+        }
+    return 0;
+}
+
+extern "C" int gpmi_probe_mfma(gpmi_ctx *c, const double *A64, const double *B64, double *out256)
+{
+    ENTER(c);
+    if (!A64 || !B64 || !out256) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *d;
+    int rc;
+    if ((rc = stage_buf(c, 0, 512 * sizeof(double), &d))) return rc;
+    HIPCHK(hipMemcpyAsync(d, A64, 64 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d + 64, B64, 64 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_probe_mfma(c->stream, d, d + 64, d + 128);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out256, d + 128, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_probe_mfma_peak(gpmi_ctx *c, int iters, double *tflops)
+{
+    ENTER(c);
+    if (iters <= 0 || !tflops) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *d;
+    int rc, blocks = 0, threads = 0;
+    if ((rc = stage_buf(c, 0, 64, &d))) return rc;
+    launch_probe_peak(c->stream, d, 16, &blocks, &threads);  // warm-up
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    launch_probe_peak(c->stream, d, iters, &blocks, &threads);
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    const double flops = (double)blocks * (threads / 64) * (double)iters * 8.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return 0;
+}

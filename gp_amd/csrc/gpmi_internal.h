@@ -1,0 +1,97 @@
+// Internal declarations shared by the libgpmi translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gpmi.h"
+
+#define GPMI_NB 128          // inner panel width == diagonal-block order
+#define GPMI_FPACK 9216      // doubles in one packed panel-factor buffer (36 tiles x 256)
+#define GPMI_MAXD 8          // dimensions carried inline in kernel arguments
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct SeParams {            // squared-exponential hyper-parameters, kernel-argument resident
+    double a2;               // alpha^2
+    double inv_ell[GPMI_MAXD];
+    int D;
+};
+
+struct gpmi_ctx {
+    int device;
+    int pid;
+    hipStream_t own_stream;
+    hipStream_t stream;      // stream in use (own or caller's)
+    // factorisation workspace: column-major, leading dimension ld, ncols columns (+ slack)
+    double *W;
+    size_t W_bytes;
+    int ld, ncols;
+    double *Fpack;           // packed factors of the current diagonal block
+    double *scratch;         // small device scratch (results, staging)
+    size_t scratch_bytes;
+    int *d_info;
+    double *d_out;           // 3 doubles
+    // generic device staging buffers for the host-pointer API
+    double *stage[4];
+    size_t stage_bytes[4];
+    int nb_outer;            // outer panel width (multiple of GPMI_NB)
+    int timing;
+    hipEvent_t ev[4];
+    double last_ms[3];
+    // per-kernel HIP-event timing (bench): category 0 covariance build, 1 trailing SYRK,
+    // 2 panel kernels (diag potrf + panel solve + in-block update)
+    int ktiming;
+    void *ktimer;            // KTimer*
+};
+
+// event-pair recorder; begin/end bracket one launch on the context's stream
+void kt_begin(gpmi_ctx *c, int cat);
+void kt_end(gpmi_ctx *c, int cat, double work);
+
+// ---- error plumbing -------------------------------------------------------
+int gpmi_fail(int code, const char *fmt, ...);
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return gpmi_fail(GPMI_EHIP, "%s failed: %s (%s:%d)", #expr,               \
+                             hipGetErrorString(e_), __FILE__, __LINE__);               \
+    } while (0)
+
+// ---- kernel launchers (se_kernels.hip) -------------------------------------
+// K (n x m, ldk) from device points; Y == X when dY == nullptr.
+void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
+                   const SeParams &p, double diag_add, int lower, double *dK, size_t ldk);
+void launch_deriv_cov(hipStream_t s, int kind, const double *dx, int n, const double *dy, int m,
+                      double a2, double l, int compat, int lower, double *dK, size_t ldk);
+void launch_deriv_elem(hipStream_t s, int kind, const double *tj, const double *tk, size_t len,
+                       double l, double *out);
+// joint 2n x 2n [[QQ+s2 I, QR],[RQ, RR]] + jitter I; lower != 0 writes i >= j only
+void launch_joint_cov(hipStream_t s, const double *dt, int n, double a2, double l, double s2,
+                      double jitter, int compat, int lower, double *dK, size_t ldk);
+void launch_set_row(hipStream_t s, double *W, size_t ld, int row, const double *src, int n,
+                    int ntotal);  // W[row, j] = j < n ? src[j] : 0, j < ntotal
+void launch_copy_matrix(hipStream_t s, const double *src, size_t lds, double *dst, size_t ldd,
+                        int rows, int cols, int mode);  // mode 0 full, 1 lower (upper zero), 2 lower->symmetric
+void launch_add_diag(hipStream_t s, double *A, size_t ld, int n, double v);
+void launch_transpose(hipStream_t s, const double *src, size_t lds, double *dst, size_t ldd, int rows, int cols);
+void launch_phi_mask(hipStream_t s, double *B, size_t ld, int n); // keep upper, halve diag, zero strict lower
+
+// ---- kernel launchers (chol_kernels.hip) -----------------------------------
+// Factor the first nfac columns of the M x ncol lower-stored matrix in W (right-looking,
+// blocked); rows nfac..M-1 become L21 / the Schur complement of the trailing block.
+int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int nfac, int *d_info,
+                         double *Fpack_all /* nullable: keep every block's packed factors */);
+// X <- X * L^-T for the rows [row0, M) of columns [0, n) using packed factors saved by a
+// previous launch_potrf_partial(..., Fpack_all)
+int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
+                      int mrows, const double *Fpack_all);
+// C (M x N) = beta_is_one ? C - A B^T : A B^T   (A: M x K, B: N x K, column-major)
+void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
+                    double *C, size_t ldc, int M, int N, int K, int accumulate_minus);
+void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all);
+void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0, int m, double scale, double *out);
+void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
+                           const int *d_info, double *d_out3, int *d_info_out);
+void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f);
+void launch_probe_mfma(hipStream_t s, const double *A, const double *B, double *D);
+void launch_probe_peak(hipStream_t s, double *sink, int iters, int *blocks, int *threads);

@@ -1,0 +1,318 @@
+// Covariance-matrix builders for gfx950: HBM-write-bound kernels.
+//
+// One workgroup (256 threads = 4 wave64) owns a 64-row x 64-column tile of the
+// column-major output.  Lane tx (0..31) owns two consecutive rows, so a wave
+// writes 2 columns x 512 contiguous bytes per store instruction (whole 128-B
+// lines, 16 B per lane); the 8 column groups of the workgroup walk 8 columns
+// each.  The input points are tiny (n x D doubles) and stay in L1/L2: the row
+// coordinates live in registers, the column coordinates are wave-uniform
+// broadcast loads.  One exp per element; for the joint [value; derivative]
+// matrix one exp feeds all four blocks.
+//
+// Reference formulas: R/kernels.R:19-32, derivative_kernels.R:39-73,
+// R/ode_gp_library.R:29-30, Stan cov_exp_quad (models/fit_hyperparameters.stan:19).
+#include "gpmi_internal.h"
+
+namespace {
+
+constexpr int TILE = 64;
+
+__device__ __forceinline__ void store_pair(double *p, double v0, double v1, bool ok0, bool ok1, bool vec)
+{
+    if (ok0 && ok1 && vec) {
+        *reinterpret_cast<double2 *>(p) = make_double2(v0, v1);
+    } else {
+        if (ok0) p[0] = v0;
+        if (ok1) p[1] = v1;
+    }
+}
+
+// K[i,j] = a2 * exp(-1/2 sum_d ((X[i,d]-Y[j,d]) * inv_ell[d])^2), diag_add on i == j if same.
+template <int DT>
+__global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, int n, int ldx,
+                                                const double *__restrict__ Y, int m, int ldy,
+                                                SeParams p, double diag_add, int same, int lower,
+                                                double *__restrict__ K, size_t ldk, int vec)
+{
+    const int D = (DT > 0) ? DT : p.D;
+    const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
+    if (lower && col0 > row0 + TILE - 1) return;  // tile strictly above the diagonal
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r = row0 + 2 * tx;
+    const bool ok0 = r < n, ok1 = r + 1 < n;
+    double x0[GPMI_MAXD], x1[GPMI_MAXD];
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) {
+        if (d < D) {
+            x0[d] = ok0 ? X[(size_t)r + (size_t)d * ldx] * p.inv_ell[d] : 0.0;
+            x1[d] = ok1 ? X[(size_t)r + 1 + (size_t)d * ldx] * p.inv_ell[d] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = col0 + ty * 8 + q;
+        if (c >= m) break;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int d = 0; d < GPMI_MAXD; ++d) {
+            if (d < D) {
+                const double yv = Y[(size_t)c + (size_t)d * ldy] * p.inv_ell[d];
+                const double d0 = x0[d] - yv, d1 = x1[d] - yv;
+                s0 = fma(d0, d0, s0);
+                s1 = fma(d1, d1, s1);
+            }
+        }
+        double v0 = p.a2 * exp(-0.5 * s0), v1 = p.a2 * exp(-0.5 * s1);
+        if (same) {
+            if (r == c) v0 = p.a2 + diag_add;  // Stan: diagonal exactly alpha^2 (+ sigma^2)
+            if (r + 1 == c) v1 = p.a2 + diag_add;
+        }
+        const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
+        store_pair(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
+    }
+}
+
+// derivative_kernels.R:39-73 with unit amplitude; r = tj - tk, e = exp(-r^2/(2 l^2)).
+__device__ __forceinline__ double deriv_val(int kind, double tj, double tk, double l2)
+{
+    if (kind == GPMI_RQ || kind == GPMI_TQ || kind == GPMI_TR) {  // :47-49, :59-61, :67-69
+        const double t = tj; tj = tk; tk = t;
+        kind -= 1;
+    }
+    const double r = tj - tk;
+    const double e = exp(-(r * r / (2 * l2)));
+    switch (kind) {
+    case GPMI_QQ: return e;                                                       // :39-41
+    case GPMI_QR: return (e * r) / l2;                                            // :43-45
+    case GPMI_RR: return e / l2 - (e * r * r) / (l2 * l2);                        // :51-53
+    case GPMI_QT: return -(e / l2) + (e * r * r) / (l2 * l2);                     // :55-57
+    case GPMI_RT: return (3 * e * r) / (l2 * l2) - (e * r * r * r) / (l2 * l2 * l2);  // :63-65
+    default:      // GPMI_TT :71-73
+        return (3 * e) / (l2 * l2) - (6 * e * r * r) / (l2 * l2 * l2) +
+               (e * r * r * r * r) / (l2 * l2 * l2 * l2);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_deriv_cov(int kind, const double *__restrict__ x, int n,
+                                                   const double *__restrict__ y, int m, double a2,
+                                                   double l2, int compat, int lower,
+                                                   double *__restrict__ K, size_t ldk, int vec)
+{
+    const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
+    if (lower && col0 > row0 + TILE - 1) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r = row0 + 2 * tx;
+    const bool ok0 = r < n, ok1 = r + 1 < n;
+    const double x0 = ok0 ? x[r] : 0.0, x1 = ok1 ? x[r + 1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = col0 + ty * 8 + q;
+        if (c >= m) break;
+        const double yv = y[c];
+        double v0, v1;
+        if (compat && kind == GPMI_RR) {  // R/kernels.R:31 as written: alpha^2 on the first term only
+            const double r0 = x0 - yv, r1 = x1 - yv;
+            const double e0 = exp(-(r0 * r0 / (2 * l2))), e1 = exp(-(r1 * r1 / (2 * l2)));
+            v0 = a2 * e0 / l2 - (e0 * r0 * r0) / (l2 * l2);
+            v1 = a2 * e1 / l2 - (e1 * r1 * r1) / (l2 * l2);
+        } else {
+            v0 = a2 * deriv_val(kind, x0, yv, l2);
+            v1 = a2 * deriv_val(kind, x1, yv, l2);
+        }
+        const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
+        store_pair(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_deriv_elem(int kind, const double *__restrict__ tj,
+                                                    const double *__restrict__ tk, size_t len,
+                                                    double l2, double *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = deriv_val(kind, tj[i], tk[i], l2);
+}
+
+// Joint covariance of order 2n, rows/cols ordered [values; derivatives]
+// (R/ode_gp_library.R:29-30): one exp per point pair feeds QQ, QR, RQ, RR.
+__global__ __launch_bounds__(256) void k_joint_cov(const double *__restrict__ t, int n, double a2,
+                                                   double l2, double s2, double jitter, int compat,
+                                                   int lower, double *__restrict__ K, size_t ldk, int vec)
+{
+    const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r = row0 + 2 * tx;
+    const bool ok0 = r < n, ok1 = r + 1 < n;
+    const double x0 = ok0 ? t[r] : 0.0, x1 = ok1 ? t[r + 1] : 0.0;
+    const double il2 = 1.0 / l2;
+    const double a2rr = compat ? 1.0 : a2;  // R/kernels.R:31 precedence bug when compat
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = col0 + ty * 8 + q;
+        if (c >= n) break;
+        const double yv = t[c];
+        const double r0 = x0 - yv, r1 = x1 - yv;
+        const double e0 = exp(-(r0 * r0 / (2 * l2))), e1 = exp(-(r1 * r1 / (2 * l2)));
+        double qq0 = a2 * e0, qq1 = a2 * e1;
+        const double qr0 = a2 * e0 * r0 * il2, qr1 = a2 * e1 * r1 * il2;
+        double rr0 = a2 * e0 * il2 - a2rr * e0 * r0 * r0 * il2 * il2;
+        double rr1 = a2 * e1 * il2 - a2rr * e1 * r1 * r1 * il2 * il2;
+        if (r == c) { qq0 += s2 + jitter; rr0 += jitter; }
+        if (r + 1 == c) { qq1 += s2 + jitter; rr1 += jitter; }
+        const bool lo0 = !lower || r >= c, lo1 = !lower || r + 1 >= c;
+        // QQ block (rows 0..n, cols 0..n) and RR block (rows n.., cols n..): lower-filtered
+        store_pair(K + (size_t)r + (size_t)c * ldk, qq0, qq1, ok0 && lo0, ok1 && lo1, vec != 0);
+        store_pair(K + (size_t)(n + r) + (size_t)(n + c) * ldk, rr0, rr1, ok0 && lo0, ok1 && lo1,
+                   vec != 0 && (n % 2 == 0));
+        // RQ block, rows n.., cols 0..n: t(UD)[i,j] = QR(t_j, t_i) = -qr; entirely below the diagonal
+        store_pair(K + (size_t)(n + r) + (size_t)c * ldk, -qr0, -qr1, ok0, ok1, vec != 0 && (n % 2 == 0));
+        // QR block, rows 0..n, cols n..: entirely above the diagonal
+        if (!lower) store_pair(K + (size_t)r + (size_t)(n + c) * ldk, qr0, qr1, ok0, ok1, vec != 0);
+    }
+}
+
+__global__ void k_set_row(double *W, size_t ld, int row, const double *src, int n, int ntotal)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < ntotal) W[(size_t)row + (size_t)j * ld] = (j < n) ? src[j] : 0.0;
+}
+
+// mode 0: plain copy; 1: lower triangle, strict upper zeroed; 2: lower triangle mirrored (symmetric out)
+__global__ __launch_bounds__(256) void k_copy_matrix(const double *__restrict__ src, size_t lds,
+                                                     double *__restrict__ dst, size_t ldd, int rows,
+                                                     int cols, int mode)
+{
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (r >= rows) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q;
+        if (c >= cols) break;
+        double v;
+        if (mode == 0) v = src[(size_t)r + (size_t)c * lds];
+        else if (mode == 1) v = (r >= c) ? src[(size_t)r + (size_t)c * lds] : 0.0;
+        else v = (r >= c) ? src[(size_t)r + (size_t)c * lds] : src[(size_t)c + (size_t)r * lds];
+        dst[(size_t)r + (size_t)c * ldd] = v;
+    }
+}
+
+__global__ void k_add_diag(double *A, size_t ld, int n, double v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[(size_t)i * (ld + 1)] += v;
+}
+
+__global__ __launch_bounds__(256) void k_transpose(const double *__restrict__ src, size_t lds,
+                                                   double *__restrict__ dst, size_t ldd, int rows, int cols)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int q = ty; q < 32; q += 8) {
+        const int r = r0 + tx, c = c0 + q;
+        tile[q][tx] = (r < rows && c < cols) ? src[(size_t)r + (size_t)c * lds] : 0.0;
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {
+        const int c = c0 + tx, r = r0 + q;  // dst[c, r] = src[r, c]
+        if (r < rows && c < cols) dst[(size_t)c + (size_t)r * ldd] = tile[tx][q];
+    }
+}
+
+// B symmetric n x n -> Phi(B)^T stored as the upper triangle: keep i < j, halve i == j, zero i > j
+__global__ __launch_bounds__(256) void k_phi_mask(double *B, size_t ld, int n)
+{
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (r >= n) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q;
+        if (c >= n) break;
+        double *p = B + (size_t)r + (size_t)c * ld;
+        if (r > c) *p = 0.0;
+        else if (r == c) *p = 0.5 * *p;
+    }
+}
+
+inline bool vec_ok(const void *p, size_t ld) { return ((uintptr_t)p % 16 == 0) && (ld % 2 == 0); }
+
+}  // namespace
+
+void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
+                   const SeParams &p, double diag_add, int lower, double *dK, size_t ldk)
+{
+    if (n <= 0 || m <= 0) return;
+    const int same = (dY == nullptr);
+    if (same) { dY = dX; ldy = ldx; }
+    dim3 grid((n + TILE - 1) / TILE, (m + TILE - 1) / TILE);
+    const int vec = vec_ok(dK, ldk);
+    switch (p.D) {
+    case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
+    case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
+    case 3: hipLaunchKernelGGL(k_se_cov<3>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
+    default: hipLaunchKernelGGL(k_se_cov<0>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
+    }
+}
+
+void launch_deriv_cov(hipStream_t s, int kind, const double *dx, int n, const double *dy, int m,
+                      double a2, double l, int compat, int lower, double *dK, size_t ldk)
+{
+    if (n <= 0 || m <= 0) return;
+    dim3 grid((n + TILE - 1) / TILE, (m + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_deriv_cov, grid, 256, 0, s, kind, dx, n, dy, m, a2, l * l, compat, lower, dK, ldk,
+                       (int)vec_ok(dK, ldk));
+}
+
+void launch_deriv_elem(hipStream_t s, int kind, const double *tj, const double *tk, size_t len,
+                       double l, double *out)
+{
+    if (len == 0) return;
+    size_t blocks = (len + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_deriv_elem, dim3((unsigned)blocks), 256, 0, s, kind, tj, tk, len, l * l, out);
+}
+
+void launch_joint_cov(hipStream_t s, const double *dt, int n, double a2, double l, double s2,
+                      double jitter, int compat, int lower, double *dK, size_t ldk)
+{
+    if (n <= 0) return;
+    dim3 grid((n + TILE - 1) / TILE, (n + TILE - 1) / TILE);
+    hipLaunchKernelGGL(k_joint_cov, grid, 256, 0, s, dt, n, a2, l * l, s2, jitter, compat, lower, dK, ldk,
+                       (int)vec_ok(dK, ldk));
+}
+
+void launch_set_row(hipStream_t s, double *W, size_t ld, int row, const double *src, int n, int ntotal)
+{
+    if (ntotal <= 0) return;
+    hipLaunchKernelGGL(k_set_row, dim3((ntotal + 255) / 256), 256, 0, s, W, ld, row, src, n, ntotal);
+}
+
+void launch_copy_matrix(hipStream_t s, const double *src, size_t lds, double *dst, size_t ldd,
+                        int rows, int cols, int mode)
+{
+    if (rows <= 0 || cols <= 0) return;
+    dim3 grid((rows + 63) / 64, (cols + 15) / 16);
+    hipLaunchKernelGGL(k_copy_matrix, grid, 256, 0, s, src, lds, dst, ldd, rows, cols, mode);
+}
+
+void launch_add_diag(hipStream_t s, double *A, size_t ld, int n, double v)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256), 256, 0, s, A, ld, n, v);
+}
+
+void launch_transpose(hipStream_t s, const double *src, size_t lds, double *dst, size_t ldd, int rows, int cols)
+{
+    if (rows <= 0 || cols <= 0) return;
+    dim3 grid((rows + 31) / 32, (cols + 31) / 32);
+    hipLaunchKernelGGL(k_transpose, grid, 256, 0, s, src, lds, dst, ldd, rows, cols);
+}
+
+void launch_phi_mask(hipStream_t s, double *B, size_t ld, int n)
+{
+    if (n <= 0) return;
+    dim3 grid((n + 63) / 64, (n + 15) / 16);
+    hipLaunchKernelGGL(k_phi_mask, grid, 256, 0, s, B, ld, n);
+}

@@ -1,0 +1,202 @@
+/*
+ * gpmi.h -- C ABI of libgpmi: the MI355X (gfx950) implementation of the exact-GP
+ * marginal-likelihood hot path of bbbales2/gp.
+ *
+ * This is the drop-in boundary: what an R `.Call()` shim (r/gpmi_shim.c), an
+ * Rcpp replacement of covariance.cpp, or any FFI binds.  Plain pointers and
+ * sizes only; no C++ / torch types.  Reference interfaces replaced are cited
+ * per entry point (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - All matrices column-major doubles (R's native layout) with explicit
+ *    leading dimension.  X is n x D column-major, i.e. each input dimension is
+ *    one contiguous stream.
+ *  - Every function returns int: 0 ok; k > 0 = "leading minor of order k is not
+ *    positive definite" (LAPACK dpotrf style; mirrors base-R chol()'s error and
+ *    Stan's cholesky_decompose domain_error); < 0 = GPMI_E* (text through
+ *    gpmi_last_error()).  Nothing throws or aborts across this boundary.
+ *  - Host-buffer entry points (no suffix) take ordinary host memory, stage it
+ *    through HBM and block until the result is back: this is what `.Call`
+ *    binds.  `_dev` entry points take device pointers (e.g. torch tensors'
+ *    data_ptr()), enqueue on the context's stream and do NOT synchronise.
+ *  - A gpmi_ctx owns its device workspace and stream; it is bound to one GPU
+ *    and to the creating process (HIP state does not survive fork(): calls
+ *    from a forked child -- e.g. parallel::mclapply at pendulum_fit.R:268 --
+ *    return GPMI_EFORK; create a context per process).
+ *  - There is no CPU fallback anywhere in the library: without a HIP device
+ *    gpmi_create fails with GPMI_ENODEV.
+ */
+#ifndef GPMI_H
+#define GPMI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMI_VERSION 100
+
+typedef struct gpmi_ctx gpmi_ctx;
+
+enum {
+    GPMI_OK = 0,
+    GPMI_EARG = -1,   /* bad argument                              */
+    GPMI_EHIP = -2,   /* HIP runtime error                         */
+    GPMI_ENOMEM = -3, /* device allocation failed                  */
+    GPMI_ENODEV = -4, /* no usable gfx950 device                   */
+    GPMI_EFORK = -5   /* context used from a forked child process  */
+};
+
+/* derivative-kernel selector: derivative_kernels.R:39-73 (Q value, R first,
+ * T second derivative of the process; row argument first) */
+enum {
+    GPMI_QQ = 0, GPMI_QR = 1, GPMI_RQ = 2, GPMI_RR = 3, GPMI_QT = 4,
+    GPMI_TQ = 5, GPMI_RT = 6, GPMI_TR = 7, GPMI_TT = 8
+};
+
+/* flags for gpmi_se_cov* */
+enum {
+    GPMI_FULL = 0,        /* write all n x m entries                              */
+    GPMI_LOWER = 1,       /* square case only: write i >= j, leave the rest alone */
+    GPMI_COMPAT_RR = 2    /* reproduce R/kernels.R:31's amplitude precedence bug  */
+};
+
+/* ---- library / context ------------------------------------------------ */
+int gpmi_version(void);
+const char *gpmi_last_error(void);
+int gpmi_device_count(int *count);
+int gpmi_create(gpmi_ctx **ctx, int device);
+int gpmi_destroy(gpmi_ctx *ctx);
+/* run on a caller-owned hipStream_t (NULL restores the context's own stream) */
+int gpmi_set_stream(gpmi_ctx *ctx, void *hip_stream);
+int gpmi_sync(gpmi_ctx *ctx);
+/* pre-size the factorisation workspace for matrices of order <= n_max */
+int gpmi_reserve(gpmi_ctx *ctx, int n_max);
+/* tuning knobs (0 keeps the default): outer panel width (multiple of 128) */
+int gpmi_set_option(gpmi_ctx *ctx, const char *name, int value);
+
+/* ---- covariance builders ---------------------------------------------- */
+
+/* K[i,j] = alpha^2 exp(-1/2 sum_d ((X[i,d]-Y[j,d])/ell[d])^2) (+ diag_add on
+ * i == j when X and Y are the same n points).  n_ell = 1 (isotropic) or D (ARD).
+ * Replaces QQard(X,Y,phi) R/kernels.R:11-19, QQ(x,y,phi) R/kernels.R:22-24
+ * (D = 1), Stan cov_exp_quad models/fit_hyperparameters.stan:19 and the
+ * diagonal update :21-24 / models/exact_gp.stan:20-22 (diag_add).
+ * Y == NULL means Y = X (symmetric; enables GPMI_LOWER). */
+int gpmi_se_cov(gpmi_ctx *ctx, const double *X, int n, int ldx, const double *Y, int m, int ldy,
+                int D, double alpha, const double *ell, int n_ell, double diag_add, int flags,
+                double *K, int ldk);
+int gpmi_se_cov_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, const double *dY, int m,
+                    int ldy, int D, double alpha, const double *ell, int n_ell, double diag_add,
+                    int flags, double *dK, int ldk);
+
+/* K[i,j] = alpha^2 * kind(x[i], y[j], l), 1-D inputs.  Replaces the matrix API
+ * QQ/QR/RR(x,y,phi) of R/kernels.R:22-32 (GPMI_COMPAT_RR for :31 as written)
+ * and a^2 * outer(ti, ti, FUN = kern) of pendulum_fit.R:237-240. */
+int gpmi_deriv_cov(gpmi_ctx *ctx, int kind, const double *x, int n, const double *y, int m,
+                   double alpha, double l, int flags, double *K, int ldk);
+int gpmi_deriv_cov_dev(gpmi_ctx *ctx, int kind, const double *dx, int n, const double *dy, int m,
+                       double alpha, double l, int flags, double *dK, int ldk);
+
+/* out[i] = kind(tj[i], tk[i], l): the vectorised elementwise functions
+ * QQ..TT(tj,tk,l) of derivative_kernels.R:39-73 (unit amplitude). */
+int gpmi_deriv_elem(gpmi_ctx *ctx, int kind, const double *tj, const double *tk, size_t len,
+                    double l, double *out);
+
+/* Joint [values; derivatives] covariance of order 2n,
+ * [[QQ + sigma^2 I, QR], [RQ, RR]] + jitter I   (R/ode_gp_library.R:29-30). */
+int gpmi_joint_cov(gpmi_ctx *ctx, const double *t, int n, double alpha, double l, double sigma,
+                   double jitter, int flags, double *K, int ldk);
+
+/* ---- dense factorisation ---------------------------------------------- */
+
+/* In-place lower Cholesky A = L L^T (strict upper triangle zeroed on return,
+ * like Stan's cholesky_decompose: models/fit_hyperparameters.stan:25,
+ * models/exact_gp.stan:23; base-R chol() returns t(L)). */
+int gpmi_potrf(gpmi_ctx *ctx, double *A, int n, int lda);
+int gpmi_potrf_dev(gpmi_ctx *ctx, double *dA, int n, int lda, int *d_info);
+
+/* f = L z (models/exact_gp.stan:25) and z = L^-1 b (mdivide_left_tri_low inside
+ * multi_normal_cholesky, models/fit_hyperparameters.stan:31). */
+int gpmi_trmv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *z, double *f);
+int gpmi_trsv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *b, double *z);
+
+/* ---- marginal likelihood ---------------------------------------------- */
+
+/* One evaluation of models/fit_hyperparameters.stan:18-32 with double inputs:
+ * Sigma = cov_exp_quad(X, alpha, rho) + (sigma^2 + jitter) I; L = chol(Sigma);
+ * out[0] = -1/2 z'z - sum log L_ii - n/2 log(2 pi), out[1] = sum log L_ii,
+ * out[2] = z'z, z = L^-1 y.  ell/n_ell as in gpmi_se_cov (rho == ell[0]). */
+int gpmi_logml(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+               double alpha, const double *ell, int n_ell, double sigma, double jitter,
+               double *out3);
+/* device-resident X, y; d_out3 (3 doubles) and d_info (1 int) in device memory */
+int gpmi_logml_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
+                   double alpha, const double *ell, int n_ell, double sigma, double jitter,
+                   double *d_out3, int *d_info);
+
+/* G independent hyper-parameter points (alpha[g], rho[g], sigma[g]) on the same
+ * data: out3[3*g..], info[g].  Non-PD points get NaN and info[g] = k and the
+ * grid continues.  Replaces the stan()-fit + arg-max of R/tests.R:13-27 when a
+ * grid search is acceptable; sharding over GPUs is done by the host layer
+ * (one context per device / process). */
+int gpmi_logml_grid(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+                    const double *alpha, const double *rho, const double *sigma, int G,
+                    double jitter, double *out3, int *info);
+int gpmi_logml_grid_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
+                        const double *alpha, const double *rho, const double *sigma, int G,
+                        double jitter, double *d_out3, int *d_info);
+
+/* Log marginal likelihood of stacked observations yy = [y; y'] (length 2n)
+ * under gpmi_joint_cov's matrix (BASELINE config c5). */
+int gpmi_joint_logml(gpmi_ctx *ctx, const double *t, int n, const double *yy, double alpha,
+                     double l, double sigma, double jitter, double *out3);
+int gpmi_joint_logml_dev(gpmi_ctx *ctx, const double *dt, int n, const double *dyy, double alpha,
+                         double l, double sigma, double jitter, double *d_out3, int *d_info);
+
+/* ---- Rcpp export ------------------------------------------------------ */
+
+/* rbf_cov_chol(x1, l): Sigma_ij = exp(-(xi-xj)^2/(2 l^2)) + 1e-10 I, L = chol,
+ * dLdl = dL/dl (forward-mode tangent).  covariance.cpp:9-47.  L, dLdl n x n. */
+int gpmi_rbf_cov_chol(gpmi_ctx *ctx, const double *x, int n, double l, double *L, int ldl,
+                      double *dLdl, int lddl);
+
+/* ---- GP posterior (value / derivative) -------------------------------- */
+
+/* mn = Ks (K + s2 I)^-1 y,  Kn = Kss - Ks (K + s2 I)^-1 Ks^T + jitter I with
+ * K = alpha^2 kindK(t,t), Ks = alpha^2 kindS(ts,t), Kss = alpha^2 kindSS(ts,ts)
+ * through ONE Cholesky of K + s2 I (the reference does two LU solves).
+ *  p_Xn      R/ode_gp.R:1-14     : (QQ, QQ, QQ), ts = t
+ *  p_dotXn   R/ode_gp.R:19-32    : (QQ, RQ, RR), ts = t
+ *  sample_derivs moments pendulum_fit.R:242-251 : (QQ, RQ, RR), jitter 1e-8
+ *  lorenz.Rmd:80-107 variant: separate prediction times ts.
+ * mn: m doubles; Kn: m x m (symmetric, both triangles written). */
+int gpmi_gp_condition(gpmi_ctx *ctx, const double *t, int n, const double *ts, int m,
+                      const double *y, double alpha, double l, double s2, double jitter,
+                      int kindK, int kindS, int kindSS, int flags, double *mn, double *Kn, int ldkn);
+
+/* ---- diagnostics (tests / bench) -------------------------------------- */
+
+/* Elapsed ms of the most recent evaluation's stages, measured with HIP events
+ * on the context's stream when timing is enabled via gpmi_set_option("timing",1):
+ * ms[0] covariance build, ms[1] Cholesky, ms[2] finalize; n_launch[0..2]. */
+int gpmi_last_timing(gpmi_ctx *ctx, double *ms3);
+
+/* Per-kernel HIP-event timing, enabled with gpmi_set_option("kernel_timing", 1): event
+ * pairs bracket every covariance-build launch (category 0; work = bytes written), every
+ * trailing-update SYRK launch (1; work = algorithmic flops) on the context's stream.
+ * out9[3*cat + 0..2] = launches, total ms, total work since the last reset. */
+int gpmi_kernel_timing(gpmi_ctx *ctx, int reset, double *out9);
+
+/* MFMA f64 fragment-layout probe: D = A(16x4) * B(4x16) on one wave with the
+ * library's fragment conventions; out256 row-major D[i][j].  Host buffers. */
+int gpmi_probe_mfma(gpmi_ctx *ctx, const double *A64, const double *B64, double *out256);
+/* Back-to-back v_mfma_f64_16x16x4_f64 issue-rate microbenchmark: returns
+ * achieved TFLOP/s over the whole chip. */
+int gpmi_probe_mfma_peak(gpmi_ctx *ctx, int iters, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMI_H */

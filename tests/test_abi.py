@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gpmi.h declares; without a
+GPU the product path fails loudly (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "gpmi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_build_and_exports():
+    from gp_amd import _build, _lib
+    lib = _build.build()
+    assert os.path.exists(lib)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
+    exported = set(re.findall(r" T (gpmi_[a-z0-9_]+)", out))
+    declared = _header_functions()
+    assert declared, "header parse found nothing"
+    missing = [f for f in declared if f not in exported]
+    assert not missing, missing
+    assert sorted(_lib.SYMBOLS) == declared  # python binding covers the whole header
+    h = _lib.load()
+    assert h.gpmi_version() == 100
+    # gfx950 code object is embedded
+    assert b"gfx950" in open(lib, "rb").read()
+
+
+def test_signatures_are_plain_c():
+    src = open(os.path.join(ROOT, "include", "gpmi.h")).read()
+    assert 'extern "C"' in src
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert "torch" not in code.lower() and "std::" not in code and "&" not in code
+
+
+def test_no_cpu_fallback_without_device():
+    import gp_amd
+    from gp_amd import _lib
+    if gp_amd.device_count() > 0:
+        pytest.skip("a GPU is visible; covered by the gpu tests")
+    with pytest.raises(gp_amd.GpmiError) as e:
+        gp_amd.Context(0)
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+    from gp_amd import kernels
+    with pytest.raises(gp_amd.GpmiError):
+        kernels.QQ([0.0, 1.0], [0.0, 1.0], [1.0, 1.0])
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+
+
+def test_null_context_is_an_error_not_a_crash():
+    from gp_amd import _lib
+    h = _lib.load()
+    assert h.gpmi_sync(None) == -1
+    assert b"NULL" in h.gpmi_last_error()

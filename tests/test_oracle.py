@@ -1,0 +1,169 @@
+"""CPU: pin the oracle (oracle/gp_oracle.c) against the golden fixtures and independent
+implementations before anything trusts it."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+KINDS = ["QQ", "QR", "RQ", "RR", "QT", "TQ", "RT", "TR", "TT"]
+
+
+def test_deriv_kernels_match_reference_python(orc, golden):
+    # golden/gp_derivs.json: outputs of the reference's gp_derivs.py:15-40 (a^2 folded in)
+    for c in golden["gp_derivs"]["kernel_cases"]:
+        for k in KINDS:
+            got = c["a"] ** 2 * float(orc.deriv_elem(k, c["tj"], c["tk"], c["l"]))
+            want = c["out"][k]
+            assert got == pytest.approx(want, rel=2e-15, abs=1e-300), (k, c)
+
+
+def test_posterior_matches_reference_python(orc, golden):
+    p = golden["gp_derivs"]["posterior"]
+    ts = np.array(p["ts"]); y = np.array(p["y"])
+    K = orc.deriv_cov("QQ", ts, ts, p["a"], p["l"])
+    np.testing.assert_allclose(K, np.array(p["K"]), rtol=1e-15, atol=0)
+    np.testing.assert_allclose(orc.deriv_cov("TQ", ts, ts, p["a"], p["l"]), np.array(p["KsKi_TQ"]), rtol=1e-14, atol=1e-300)
+    np.testing.assert_allclose(orc.deriv_cov("TT", ts, ts, p["a"], p["l"]), np.array(p["KsKsi_TT"]), rtol=1e-14, atol=1e-300)
+    # derivative posterior == sample_derivs moments without jitter (gp_derivs.py:97-113 uses numpy LU solve)
+    mu, cov = orc.sample_derivs_moments(ts, y, p["l"], p["a"], p["s"], jitter=0.0)
+    np.testing.assert_allclose(mu, np.array(p["mu_deriv"]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(cov, np.array(p["cov_deriv"]), rtol=0, atol=1e-9)
+    mn, Kn = orc.p_Xn(ts, y, p["a"], p["l"], p["s"])
+    np.testing.assert_allclose(mn, np.array(p["mu_value"]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Kn, np.array(p["cov_value"]), rtol=0, atol=1e-9)
+
+
+def test_logml_known_answers(orc, golden):
+    for k in golden["kat"]["kats"]:
+        x = np.array(k["x"]); y = np.array(k["y"])
+        lm, sld, q, info = orc.logml(x, y, k["alpha"], k["rho"], k["sigma"])
+        assert info == 0
+        assert lm == pytest.approx(k["logml"], rel=1e-11), k["name"]
+        assert sld == pytest.approx(k["sum_log_diag"], rel=1e-11)
+        assert q == pytest.approx(k["quad"], rel=1e-9)
+        Kc = orc.cov_exp_quad(x.reshape(len(y), -1), k["alpha"], k["rho"]) + k["sigma"] ** 2 * np.eye(len(y))
+        assert orc.cholesky(Kc)[1, 0] == pytest.approx(k["L10"], rel=1e-13)
+
+
+def test_cholesky_vs_lapack_and_blocked(orc):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 17, 130, 300):
+        A = rng.standard_normal((n, n)); A = A @ A.T + n * np.eye(n)
+        L = orc.cholesky(A)
+        np.testing.assert_allclose(L, sla.cholesky(A, lower=True), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(orc.cholesky(A, blocked=True), L, rtol=1e-12, atol=1e-13)
+        assert np.all(np.triu(L, 1) == 0)
+    with pytest.raises(ValueError) as e:
+        orc.cholesky(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    assert e.value.args[0] == 2  # leading minor of order 2
+
+
+def test_triangular_and_lu(orc):
+    rng = np.random.default_rng(1)
+    n = 40
+    A = rng.standard_normal((n, n)); A = A @ A.T + n * np.eye(n)
+    L = np.linalg.cholesky(A); b = rng.standard_normal(n)
+    np.testing.assert_allclose(orc.trsv_lower(L, b), sla.solve_triangular(L, b, lower=True), rtol=1e-12)
+    np.testing.assert_allclose(orc.trmv_lower(L, b), L @ b, rtol=1e-13)
+    B = rng.standard_normal((n, 3)); M = rng.standard_normal((n, n))
+    np.testing.assert_allclose(orc.lu_solve(M, B), np.linalg.solve(M, B), rtol=1e-9, atol=1e-11)
+
+
+def test_kernel_identities(orc):
+    x = np.linspace(-1.5, 2.0, 13); y = np.linspace(-0.7, 1.1, 7); l, a = 0.8, 1.3
+    # RQ = t(QR) (R/ode_gp.R:25); QT = -RR; symmetry of QQ, RR, TT
+    np.testing.assert_allclose(orc.deriv_cov("RQ", x, y, a, l), orc.deriv_cov("QR", y, x, a, l).T, rtol=1e-15)
+    np.testing.assert_allclose(orc.deriv_cov("QT", x, y, a, l), -orc.deriv_cov("RR", x, y, a, l), rtol=1e-15)
+    # finite differences: d/dtk QQ = QR, d/dtj QR = RR (design_notes.Rmd:10-23), d/dtk QR = QT ...
+    h = 1e-5
+    tj, tk, l = 0.3, 1.1, 0.7
+    fd = (orc.deriv_elem("QQ", tj, tk + h, l) - orc.deriv_elem("QQ", tj, tk - h, l)) / (2 * h)
+    assert fd == pytest.approx(float(orc.deriv_elem("QR", tj, tk, l)), rel=1e-8)
+    fd = (orc.deriv_elem("QR", tj + h, tk, l) - orc.deriv_elem("QR", tj - h, tk, l)) / (2 * h)
+    assert fd == pytest.approx(float(orc.deriv_elem("RR", tj, tk, l)), rel=1e-8)
+    fd = (orc.deriv_elem("RR", tj, tk + h, l) - orc.deriv_elem("RR", tj, tk - h, l)) / (2 * h)
+    assert fd == pytest.approx(float(orc.deriv_elem("RT", tj, tk, l)), rel=1e-7)
+    fd = (orc.deriv_elem("RT", tj + h, tk, l) - orc.deriv_elem("RT", tj - h, tk, l)) / (2 * h)
+    assert fd == pytest.approx(float(orc.deriv_elem("TT", tj, tk, l)), rel=1e-7)
+    l = 0.8
+    # matrix API (R/kernels.R) == a^2 * elementwise API; RR compat differs only when a != 1
+    np.testing.assert_allclose(orc.QQ(x, y, a, l), orc.deriv_cov("QQ", x, y, a, l), rtol=1e-15)
+    np.testing.assert_allclose(orc.QR(x, y, a, l), orc.deriv_cov("QR", x, y, a, l), rtol=4e-16, atol=1e-300)
+    np.testing.assert_allclose(orc.RR(x, y, a, l), orc.deriv_cov("RR", x, y, a, l), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(orc.RR(x, y, 1.0, l, compat=True), orc.RR(x, y, 1.0, l), rtol=0, atol=0)
+    assert np.max(np.abs(orc.RR(x, y, a, l, compat=True) - orc.RR(x, y, a, l))) > 1e-3
+    # QQard == QQ for D = 1 up to the last ulp; ARD vs isotropic
+    np.testing.assert_allclose(orc.QQard(x.reshape(-1, 1), y.reshape(-1, 1), a, [l]), orc.QQ(x, y, a, l), rtol=4e-15)
+    X = np.random.default_rng(2).random((9, 3)); Y = np.random.default_rng(3).random((5, 3))
+    np.testing.assert_allclose(orc.QQard(X, Y, a, [l]), orc.QQard(X, Y, a, [l, l, l]), rtol=0, atol=0)
+    d2 = ((X[:, None, :] - Y[None, :, :]) ** 2 / np.array([0.5, 1.0, 2.0]) ** 2).sum(-1)
+    np.testing.assert_allclose(orc.QQard(X, Y, a, [0.5, 1.0, 2.0]), a * a * np.exp(-0.5 * d2), rtol=1e-14)
+    # Stan cov_exp_quad: exact alpha^2 diagonal, symmetric, equals QQard off the diagonal
+    K = orc.cov_exp_quad(X, a, l)
+    assert np.all(np.diag(K) == a * a) and np.all(K == K.T)
+    np.testing.assert_allclose(K, orc.QQard(X, X, a, [l]), rtol=1e-14)
+
+
+def test_joint_cov_and_posteriors(orc):
+    t = np.linspace(-2, 2, 21); f = np.exp(t); a, l, s = 1.1, 0.9, 0.05
+    K = orc.joint_cov(t, a, l, s, 1e-6)
+    n = t.size
+    np.testing.assert_allclose(K, K.T, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(K[:n, :n], orc.QQ(t, t, a, l) + (s * s + 1e-6) * np.eye(n), rtol=1e-15)
+    np.testing.assert_allclose(K[:n, n:], orc.QR(t, t, a, l), rtol=1e-15)
+    np.testing.assert_allclose(K[n:, n:], orc.RR(t, t, a, l) + 1e-6 * np.eye(n), rtol=1e-15)
+    # direct (R/ode_gp.R:19-32) vs dense numpy
+    mn, Kn = orc.p_dotXn(t, f, a, l, s)
+    QQm, QRm, RRm = orc.QQ(t, t, a, l), orc.QR(t, t, a, l), orc.RR(t, t, a, l)
+    A = QQm + s * s * np.eye(n)
+    np.testing.assert_allclose(mn, QRm.T @ np.linalg.solve(A, f), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(Kn, RRm - QRm.T @ np.linalg.solve(A, QRm), rtol=0, atol=1e-8)
+    # joint / condMVN form (R/ode_gp_library.R:23-33) == direct form with the 1e-6 jitters
+    cm, cv = orc.p_dotXn_joint(t, f, a, l, s, 1e-6)
+    A6 = A + 1e-6 * np.eye(n)
+    np.testing.assert_allclose(cm, QRm.T @ np.linalg.solve(A6, f), rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(cv, RRm + 1e-6 * np.eye(n) - QRm.T @ np.linalg.solve(A6, QRm), rtol=0, atol=1e-8)
+    # joint log marginal == dense formula
+    yy = np.concatenate([np.sin(t), np.cos(t)])
+    lm, sld, q, info = orc.joint_logml(t, yy, a, l, s, 1e-6)
+    Kj = orc.joint_cov(t, a, l, s, 1e-6)
+    Lj = np.linalg.cholesky(Kj); z = sla.solve_triangular(Lj, yy, lower=True)
+    assert info == 0 and lm == pytest.approx(-0.5 * z @ z - np.log(np.diag(Lj)).sum() - n * np.log(2 * np.pi), rel=1e-9)
+
+
+def test_rbf_cov_chol_tangent(orc):
+    # covariance.cpp:9-47: L of exp(-(xi-xj)^2/(2 l^2)) + 1e-10 I and dL/dl; check L L^T, and the
+    # tangent against a central finite difference of the factor (well-conditioned spacing)
+    x = np.linspace(0, 6, 13); l = 0.45
+    L, dL = orc.rbf_cov_chol(x, l)
+    S = np.exp(-(x[:, None] - x[None, :]) ** 2 / (2 * l * l)) + 1e-10 * np.eye(x.size)
+    np.testing.assert_allclose(L @ L.T, S, rtol=0, atol=1e-14)
+    h = 1e-6
+    Lp, _ = orc.rbf_cov_chol(x, l + h); Lm, _ = orc.rbf_cov_chol(x, l - h)
+    np.testing.assert_allclose(dL, (Lp - Lm) / (2 * h), rtol=0, atol=2e-8)
+    # product rule: d(L L^T)/dl == dSigma/dl
+    dS = S * (x[:, None] - x[None, :]) ** 2 / l ** 3
+    np.testing.assert_allclose(dL @ L.T + L @ dL.T, dS - np.diag(np.diag(dS)), rtol=0, atol=1e-12)
+
+
+def test_approx_L_hermite(orc):
+    # covariance.cpp:49-96 / cubic_spline_test.R:13-18: cubic Hermite through (y, dy/dl) knots
+    x = np.linspace(0, 5, 9); lp = np.array([0.5, 0.7, 0.9, 1.2])
+    Ls, dLs = zip(*[orc.rbf_cov_chol(x, l) for l in lp])
+    for k, l in enumerate(lp[:-1]):
+        np.testing.assert_allclose(orc.approx_L(l + 1e-12, lp, Ls, dLs), Ls[k], rtol=0, atol=1e-9)
+    mid = orc.approx_L(0.8, lp, Ls, dLs)
+    exact, _ = orc.rbf_cov_chol(x, 0.8)
+    assert np.max(np.abs(mid - exact)) < 5e-3 and np.all(np.triu(mid, 1) == 0)
+
+
+def test_stan_lp_formula(orc):
+    import math
+    v = orc.stan_lp(-3.5, 7.25, 1.2, 0.8, 0.3)
+    want = 3.5 - 0.5 * 7.25 + 3 * math.log(0.8) - 4 * 0.8 - 0.72 - 0.045 + math.log(0.8) + math.log(1.2) + math.log(0.3)
+    assert v == pytest.approx(want, rel=1e-14)
+
+
+def test_synth_is_deterministic(orc):
+    X, y = orc.synth(50, 3); X2, y2 = orc.synth(50, 3)
+    assert np.array_equal(X, X2) and np.array_equal(y, y2)
+    assert X.min() >= 0 and X.max() < 1 and abs(np.mean(X) - 0.5) < 0.1
