@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--d", type=int, default=3)
     ap.add_argument("--nb-outer", type=int, default=0)
-    ap.add_argument("--cpu-sample-n", type=int, default=3072)
+    ap.add_argument("--cpu-sample-n", type=int, default=6144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
 #pragma unroll
     for (int d = 0; d < GPMI_MAXD; ++d) {
         if (d < D) {
-            x0[d] = ok0 ? X[(size_t)r + (size_t)d * ldx] * p.inv_ell[d] : 0.0;
-            x1[d] = ok1 ? X[(size_t)r + 1 + (size_t)d * ldx] * p.inv_ell[d] : 0.0;
+            // __dmul_rn: keep the scaling a separate rounding so that (x_i - x_j) and (x_j - x_i)
+            // are exact negatives (no fma contraction) and K comes out bit-symmetric
+            x0[d] = ok0 ? __dmul_rn(X[(size_t)r + (size_t)d * ldx], p.inv_ell[d]) : 0.0;
+            x1[d] = ok1 ? __dmul_rn(X[(size_t)r + 1 + (size_t)d * ldx], p.inv_ell[d]) : 0.0;
         }
     }
 #pragma unroll
@@ -56,8 +58,8 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
 #pragma unroll
         for (int d = 0; d < GPMI_MAXD; ++d) {
             if (d < D) {
-                const double yv = Y[(size_t)c + (size_t)d * ldy] * p.inv_ell[d];
-                const double d0 = x0[d] - yv, d1 = x1[d] - yv;
+                const double yv = __dmul_rn(Y[(size_t)c + (size_t)d * ldy], p.inv_ell[d]);
+                const double d0 = __dsub_rn(x0[d], yv), d1 = __dsub_rn(x1[d], yv);
                 s0 = fma(d0, d0, s0);
                 s1 = fma(d1, d1, s1);
             }

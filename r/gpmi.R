@@ -1,0 +1,67 @@
+# gpmi.R -- R wrappers with the reference's function names and signatures over the
+# .Call shim (r/gpmi_shim.c).  Two environments, exactly as the reference keeps two files
+# whose names collide (SURVEY section 9 Q2): source ONE of
+#   gpmi_kernels_env            <-> R/kernels.R            QQ, QR, RR, QQard (matrix API, phi list)
+#   gpmi_derivative_kernels_env <-> derivative_kernels.R   QQ..TT(tj, tk, l) (elementwise API)
+# R is not present in the build image; these wrappers are exercised through their Python
+# mirror (gp_amd/*.py), which makes the same C-ABI calls.
+
+.gpmi_kinds <- c(QQ = 0L, QR = 1L, RQ = 2L, RR = 3L, QT = 4L, TQ = 5L, RT = 6L, TR = 7L, TT = 8L)
+GPMI_COMPAT_RR <- 2L   # reproduce R/kernels.R:31 as written (alpha^2 on the first term only)
+
+gpmi_kernels_env <- local({
+  compat_kernels_R_RR <- FALSE
+  QQ <- function(x, y, phi) .Call("gpmi_R_deriv_cov", 0L, as.double(x), as.double(y), phi[[1]], phi[[2]], 0L)
+  QR <- function(x, y, phi) .Call("gpmi_R_deriv_cov", 1L, as.double(x), as.double(y), phi[[1]], phi[[2]], 0L)
+  RR <- function(x, y, phi) .Call("gpmi_R_deriv_cov", 3L, as.double(x), as.double(y), phi[[1]], phi[[2]],
+                                  if (compat_kernels_R_RR) GPMI_COMPAT_RR else 0L)
+  QQard <- function(X, Y, phi) .Call("gpmi_R_se_cov", as.matrix(X), as.matrix(Y), phi[[1]], as.double(phi[[2]]))
+  # R/ode_gp.R:1-32 (mn/Kn) and R/ode_gp_library.R:4-33 (condMean/condVar): both name pairs
+  .cond <- function(tn, Xn, phi_n, sigma_n, kinds, joint) {
+    jit <- if (joint) 1e-6 else 0
+    r <- .Call("gpmi_R_gp_condition", as.double(tn), as.double(tn), as.double(Xn), phi_n[[1]], phi_n[[2]],
+               sigma_n^2 + jit, jit, kinds, if (compat_kernels_R_RR) GPMI_COMPAT_RR else 0L)
+    list(mn = r[[1]], Kn = r[[2]], condMean = as.numeric(r[[1]]), condVar = r[[2]])
+  }
+  p_Xn <- function(tn, Xn, phi_n, sigma_n, joint = FALSE) .cond(tn, Xn, phi_n, sigma_n, c(0L, 0L, 0L), joint)
+  p_dotXn <- function(tn, Xn, phi_n, sigma_n, joint = FALSE) .cond(tn, Xn, phi_n, sigma_n, c(0L, 2L, 3L), joint)
+  environment()
+})
+
+gpmi_derivative_kernels_env <- local({
+  mk <- function(k) function(tj, tk, l) {
+    n <- max(length(tj), length(tk))
+    .Call("gpmi_R_deriv_elem", k, rep_len(as.double(tj), n), rep_len(as.double(tk), n), l)
+  }
+  QQ <- mk(0L); QR <- mk(1L); RQ <- mk(2L); RR <- mk(3L); QT <- mk(4L)
+  TQ <- mk(5L); RT <- mk(6L); TR <- mk(7L); TT <- mk(8L)
+  # matrix-level fast path for a^2 * outer(ti, ti, FUN = kern_fixed_l(kern, l)), pendulum_fit.R:237-240
+  se_deriv_cov <- function(t1, t2, l, alpha, block) .Call("gpmi_R_deriv_cov", .gpmi_kinds[[block]], as.double(t1),
+                                                          as.double(t2), alpha, l, 0L)
+  # sample_derivs(params, ynoise, ti): pendulum_fit.R:227-255 with ONE Cholesky on the GPU
+  sample_derivs <- function(params, ynoise, ti) {
+    r <- .Call("gpmi_R_gp_condition", as.double(ti), as.double(ti), as.double(ynoise), params[2], params[1],
+               params[3]^2, 1e-8, c(0L, 2L, 3L), 0L)
+    MASS::mvrnorm(1, as.numeric(r[[1]]), r[[2]])
+  }
+  environment()
+})
+
+# covariance.cpp:9-47
+rbf_cov_chol <- function(x1, l_) .Call("gpmi_R_rbf_cov_chol", as.double(x1), l_)
+
+# models/fit_hyperparameters.stan:18-32 as plain functions
+gp_log_marginal <- function(X, y, alpha, rho, sigma, jitter = 0)
+  .Call("gpmi_R_logml", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)[1]
+
+gp_log_marginal_grid <- function(X, y, alpha, rho_vec, sigma_vec, jitter = 0) {
+  g <- expand.grid(rho = rho_vec, sigma = sigma_vec)
+  r <- .Call("gpmi_R_logml_grid", as.matrix(X), as.double(y), rep(alpha, nrow(g)), g$rho, g$sigma, jitter)
+  matrix(r[[1]][1, ], nrow = length(rho_vec), ncol = length(sigma_vec))
+}
+
+# arg-max over the grid: mirror of get_ml_from_stan_samples, R/tests.R:21-27
+get_ml_from_grid <- function(values, alpha, rho_vec, sigma_vec) {
+  idx <- which(values == max(values, na.rm = TRUE), arr.ind = TRUE)[1, ]
+  list(alpha = alpha, rho = rho_vec[idx[1]], sigma = sigma_vec[idx[2]])
+}

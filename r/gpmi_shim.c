@@ -1,0 +1,144 @@
+/*
+ * gpmi_shim.c -- R `.Call()` shim over the libgpmi C ABI (include/gpmi.h).
+ *
+ * Reference-side binding a maintainer adds to bbbales2/gp:
+ *     R CMD SHLIB -o gpmi_shim.so gpmi_shim.c -I<repo>/include -L<repo>/gp_amd/csrc -lgpmi
+ *     dyn.load("gpmi_shim.so"); source("r/gpmi.R")
+ * R is absent from the build image (no Rinternals.h), so this file is NOT compiled by
+ * __graft_entry__.build(); it is a thin translation layer whose every code path is one
+ * C-ABI call that tests/ exercise through ctypes.  Rules it follows:
+ *   - arguments of .Call are shared, never modified (copy-on-modify semantics);
+ *   - outputs are allocated with Rf_allocMatrix / Rf_allocVector under PROTECT;
+ *   - the ABI returns a status; all C resources are released BEFORE Rf_error (a longjmp);
+ *   - one lazily created context per process (HIP does not survive fork():
+ *     parallel::mclapply children get GPMI_EFORK -> re-create after a PID change).
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <unistd.h>
+
+#include "gpmi.h"
+
+static gpmi_ctx *g_ctx = NULL;
+static int g_pid = 0;
+
+static gpmi_ctx *ctx(void)
+{
+    if (g_ctx && g_pid != (int)getpid()) g_ctx = NULL; /* forked child: parent's handle is unusable */
+    if (!g_ctx) {
+        int rc = gpmi_create(&g_ctx, 0);
+        if (rc) Rf_error("libgpmi: %s", gpmi_last_error());
+        g_pid = (int)getpid();
+    }
+    return g_ctx;
+}
+
+static void check(int rc)
+{
+    if (rc > 0) Rf_error("the leading minor of order %d is not positive definite", rc); /* base-R chol() wording */
+    if (rc < 0) Rf_error("libgpmi: %s", gpmi_last_error());
+}
+
+/* QQard(X, Y, phi): R/kernels.R:11-19.  X n x D, Y m x D, alpha scalar, ell length 1 or D */
+SEXP gpmi_R_se_cov(SEXP X, SEXP Y, SEXP alpha, SEXP ell)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X), m = Rf_nrows(Y);
+    SEXP K = PROTECT(Rf_allocMatrix(REALSXP, n, m));
+    int rc = gpmi_se_cov(ctx(), REAL(X), n, n, REAL(Y), m, m, D, Rf_asReal(alpha), REAL(ell), Rf_length(ell),
+                         0.0, GPMI_FULL, REAL(K), n > 0 ? n : 1);
+    UNPROTECT(1);
+    check(rc);
+    return K;
+}
+
+/* QQ / QR / RR (x, y, phi) of R/kernels.R:22-32 and a^2 * outer(x, y, kern) of pendulum_fit.R:237-240 */
+SEXP gpmi_R_deriv_cov(SEXP kind, SEXP x, SEXP y, SEXP alpha, SEXP l, SEXP flags)
+{
+    int n = Rf_length(x), m = Rf_length(y);
+    SEXP K = PROTECT(Rf_allocMatrix(REALSXP, n, m));
+    int rc = gpmi_deriv_cov(ctx(), Rf_asInteger(kind), REAL(x), n, REAL(y), m, Rf_asReal(alpha), Rf_asReal(l),
+                            Rf_asInteger(flags), REAL(K), n > 0 ? n : 1);
+    UNPROTECT(1);
+    check(rc);
+    return K;
+}
+
+/* QQ..TT(tj, tk, l) of derivative_kernels.R:39-73 (vectors already recycled to equal length by the R wrapper) */
+SEXP gpmi_R_deriv_elem(SEXP kind, SEXP tj, SEXP tk, SEXP l)
+{
+    R_xlen_t len = Rf_xlength(tj);
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, len));
+    int rc = gpmi_deriv_elem(ctx(), Rf_asInteger(kind), REAL(tj), REAL(tk), (size_t)len, Rf_asReal(l), REAL(out));
+    UNPROTECT(1);
+    check(rc);
+    return out;
+}
+
+/* list(L=, dLdl=) = rbf_cov_chol(x1, l_): covariance.cpp:9-47 */
+SEXP gpmi_R_rbf_cov_chol(SEXP x, SEXP l)
+{
+    int n = Rf_length(x);
+    SEXP L = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+    SEXP dL = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+    int rc = gpmi_rbf_cov_chol(ctx(), REAL(x), n, Rf_asReal(l), REAL(L), n, REAL(dL), n);
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2)), names = PROTECT(Rf_allocVector(STRSXP, 2));
+    SET_VECTOR_ELT(out, 0, L); SET_VECTOR_ELT(out, 1, dL);
+    SET_STRING_ELT(names, 0, Rf_mkChar("L")); SET_STRING_ELT(names, 1, Rf_mkChar("dLdl"));
+    Rf_setAttrib(out, R_NamesSymbol, names);
+    UNPROTECT(4);
+    check(rc);
+    return out;
+}
+
+/* c(logml, sum log L_ii, z'z): one evaluation of models/fit_hyperparameters.stan:18-32 */
+SEXP gpmi_R_logml(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X);
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, 3));
+    int rc = gpmi_logml(ctx(), REAL(X), n, n, D, REAL(y), Rf_asReal(alpha), REAL(ell), Rf_length(ell),
+                        Rf_asReal(sigma), Rf_asReal(jitter), REAL(out));
+    UNPROTECT(1);
+    check(rc);
+    return out;
+}
+
+/* G x 3 matrix + info for a hyper-parameter grid (non-PD points NaN, grid continues) */
+SEXP gpmi_R_logml_grid(SEXP X, SEXP y, SEXP alpha, SEXP rho, SEXP sigma, SEXP jitter)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X), G = Rf_length(rho);
+    SEXP res = PROTECT(Rf_allocMatrix(REALSXP, 3, G)), info = PROTECT(Rf_allocVector(INTSXP, G));
+    int rc = gpmi_logml_grid(ctx(), REAL(X), n, n, D, REAL(y), REAL(alpha), REAL(rho), REAL(sigma), G,
+                             Rf_asReal(jitter), REAL(res), INTEGER(info));
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
+    SET_VECTOR_ELT(out, 0, res); SET_VECTOR_ELT(out, 1, info);
+    UNPROTECT(3);
+    check(rc);
+    return out;
+}
+
+/* list(mn, Kn): p_Xn / p_dotXn (R/ode_gp.R:1-32, R/ode_gp_library.R:4-33), sample_derivs moments
+ * (pendulum_fit.R:242-251) */
+SEXP gpmi_R_gp_condition(SEXP t, SEXP ts, SEXP y, SEXP alpha, SEXP l, SEXP s2, SEXP jitter, SEXP kinds, SEXP flags)
+{
+    int n = Rf_length(t), m = Rf_length(ts);
+    int *k = INTEGER(kinds);
+    SEXP mn = PROTECT(Rf_allocMatrix(REALSXP, m, 1)), Kn = PROTECT(Rf_allocMatrix(REALSXP, m, m));
+    int rc = gpmi_gp_condition(ctx(), REAL(t), n, REAL(ts), m, REAL(y), Rf_asReal(alpha), Rf_asReal(l), Rf_asReal(s2),
+                               Rf_asReal(jitter), k[0], k[1], k[2], Rf_asInteger(flags), REAL(mn), REAL(Kn), m);
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
+    SET_VECTOR_ELT(out, 0, mn); SET_VECTOR_ELT(out, 1, Kn);
+    UNPROTECT(3);
+    check(rc);
+    return out;
+}
+
+/* t(chol(A)) replacement: lower factor, upper zeroed (Stan convention); base-R chol() is t() of this */
+SEXP gpmi_R_potrf(SEXP A)
+{
+    int n = Rf_nrows(A);
+    SEXP L = PROTECT(Rf_duplicate(A)); /* never modify a .Call argument */
+    int rc = gpmi_potrf(ctx(), REAL(L), n, n > 0 ? n : 1);
+    UNPROTECT(1);
+    check(rc);
+    return L;
+}
