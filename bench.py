@@ -140,7 +140,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "c3: exact GP log marginal likelihood, N=%d, D=%d, SE kernel build + "
                                    "fp64 Cholesky + solve + log-det, 1 hyper-parameter point per step per GPU" % (n, D),
-                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1, "nb_outer": args.nb_outer or 256,
+                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1, "nb_outer": args.nb_outer or "auto(512)",
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
             "logml_first": float(res[warm, 0]),

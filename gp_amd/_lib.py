@@ -22,7 +22,7 @@ SYMBOLS = (
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
-    "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
+    "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
 )
 
 
@@ -289,10 +289,16 @@ class Context:
         _chk(self._lib.gpmi_probe_mfma(self._h, _p(A), _p(B), _p(out)))
         return out
 
+    def probe_syrk(self, m, k, reps=5):
+        """(avg ms per launch, TFLOP/s at m(m+1)k algorithmic flops)."""
+        ms = C.c_double(0.0)
+        _chk(self._lib.gpmi_probe_syrk(self._h, int(m), int(k), int(reps), C.byref(ms)))
+        return ms.value, m * (m + 1.0) * k / (ms.value * 1e-3) / 1e12
+
     def probe_mfma_peak(self, iters=20000):
-        t = C.c_double(0.0)
-        _chk(self._lib.gpmi_probe_mfma_peak(self._h, int(iters), C.byref(t)))
-        return t.value
+        t = C.c_double(0.0); mhz = C.c_double(0.0)
+        _chk(self._lib.gpmi_probe_mfma_peak(self._h, int(iters), C.byref(t), C.byref(mhz)))
+        return t.value, mhz.value
 
 
 _default = {}

@@ -57,6 +57,7 @@ __device__ __noinline__ int factor16(double (*s_d16)[17], double *s_inv, int lan
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] = s_d16[lr][c];
     int bad = 0;
+    double dinv[16];  // 1 / L_jj, wave-uniform
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         double d = readlane64(row[j], j);
@@ -64,8 +65,14 @@ __device__ __noinline__ int factor16(double (*s_d16)[17], double *s_inv, int lan
             if (!bad) bad = j + 1;
             d = 1.0;
         }
-        const double s = sqrt(d);
-        double cj = row[j] / s;
+        // s = sqrt(d) through one rsqrt and a Newton correction (keeps the 128-pivot critical
+        // path short: no fp64 sqrt + divide chain); multipliers use the reciprocal
+        const double ri = rsqrt(d);
+        double s = d * ri;
+        s = fma(0.5 * ri, fma(-s, s, d), s);
+        const double inv = fma(ri, fma(-s, ri, 1.0), ri);  // 1/s refined
+        dinv[j] = inv;
+        double cj = row[j] * inv;
         cj = (lr == j) ? s : cj;
         row[j] = cj;
 #pragma unroll
@@ -81,7 +88,7 @@ __device__ __noinline__ int factor16(double (*s_d16)[17], double *s_inv, int lan
         double s = (r == lr) ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < r; ++k) s = fma(-readlane64(row[k], r), x[k], s);
-        x[r] = s / readlane64(row[r], r);
+        x[r] = s * dinv[r];
     }
     if (lq == 0) {
 #pragma unroll
@@ -123,13 +130,13 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double *__restrict__ A, size
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         // (a1) owner publishes its updated diagonal tile in matrix order [row][col]
+        // (a2) then factors it and inverts the factor (LDS in, LDS out).  Same wave: LDS
+        // operations of one wave complete in order, no workgroup barrier needed in between.
         if (w == kb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = T[kb][i];
-        }
-        __syncthreads();
-        // (a2) owner factors the 16x16 tile and inverts its factor (LDS in, LDS out)
-        if (w == kb) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int bad = factor16(s_d16, s_inv, lane);
             if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
         }
@@ -250,20 +257,54 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double *__restrict__ Acol, s
 // ---------------------------------------------------------------------------
 constexpr int GT = 128, GK = 16, GP = 144;
 
-template <int MODE>
+// SYRK tile order.  Workgroups are dealt round-robin to the 8 XCDs (observed dispatch
+// behaviour; performance only), so block b runs on XCD-group b % 8 as that group's (b / 8)-th
+// workgroup.  Each group walks 8x8 SUPER-TILES of the lower triangle: the 64 tiles that are
+// resident on one XCD at a time then share 8 row-blocks and 8 column-blocks of the panel
+// through that XCD's L2 (16 blocks per 64 tiles instead of ~65 in row-major order), which
+// takes the operand stream off HBM / Infinity Cache.  Tiles of a super-tile that fall outside
+// the triangle exit at once.
+constexpr int ST = 8;
+__device__ __forceinline__ bool syrk_tile(int b, int T, int order, int &ti, int &tj)
+{
+    if (order == 0) {  // plain row-major walk of the lower triangle
+        int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= b) ++i;
+        while (i * (i + 1) / 2 > b) --i;
+        ti = i;
+        tj = b - i * (i + 1) / 2;
+        return ti < T;
+    }
+    const int xcd = b & 7, q = b >> 3;
+    const int s = (q / (ST * ST)) * 8 + xcd;       // super-tile index, row-major over the triangle
+    const int local = q % (ST * ST);
+    const int nst = (T + ST - 1) / ST;
+    if (s >= nst * (nst + 1) / 2) return false;
+    int I = (int)((sqrt(8.0 * (double)s + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= s) ++I;
+    while (I * (I + 1) / 2 > s) --I;
+    const int J = s - I * (I + 1) / 2;
+    ti = I * ST + (local % ST);
+    tj = J * ST + (local / ST);
+    return ti < T && tj <= ti;
+}
+__host__ inline int syrk_grid(int T, int order)
+{
+    if (order == 0) return T * (T + 1) / 2;
+    const int nst = (T + ST - 1) / ST;
+    const int ns = nst * (nst + 1) / 2;
+    return ((ns + 7) / 8) * 8 * ST * ST;
+}
+
+template <int MODE, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
                                                  const double *__restrict__ B, size_t ldb,
-                                                 double *__restrict__ C, size_t ldc, int M, int N, int K)
+                                                 double *__restrict__ C, size_t ldc, int M, int N, int K, int order)
 {
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
     int ti, tj;
     if (MODE == 1) {
-        const int t = blockIdx.x;
-        int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        while (i * (i + 1) / 2 > t) --i;
-        ti = i;
-        tj = t - i * (i + 1) / 2;
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -300,13 +341,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         }
     };
 
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * GK);
-        const int st = kt & 1;
-        const int klim = K - kt * GK;
+    auto compute = [&](int st, int klim) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int kr = kk * 4 + lq;
@@ -323,6 +358,64 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
+        }
+    };
+
+    issue(0, 0);
+    const int nloop = (EPI == 1) ? nk - 1 : nk;
+    for (int kt = 0; kt < nloop; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * GK);
+        compute(kt & 1, K - kt * GK);
+    }
+
+    if (EPI == 1) {
+        // Last k-step peeled.  For a tile wholly inside the matrix the first half of the C
+        // tile (32 loads per lane, uniform offsets from one base) is issued under that step --
+        // the staging loads are all retired by then -- and the second half right after the
+        // first half's stores: one memory round trip is exposed per tile instead of four.
+        const bool interior = (m0 + GT <= M) && (n0 + GT <= N);
+        double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 64 + lq) * ldc;
+        double ch[2][4][4];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (MODE != 2 && interior) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ch[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
+        }
+        compute((nk - 1) & 1, K - (nk - 1) * GK);
+        if (interior) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc] =
+                            (MODE == 2) ? acc[tn][tm][i] : ch[tn][tm][i] - acc[tn][tm][i];
+            if (MODE != 2) {
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            ch[tn][tm][i] = cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc];
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc] =
+                            (MODE == 2) ? acc[tn + 2][tm][i] : ch[tn][tm][i] - acc[tn + 2][tm][i];
+            return;
         }
     }
 
@@ -354,6 +447,347 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// GEMM NT v2: same 128x128 tile and LDS image, 8 waves (2 m x 4 n, 64 x 32 outputs per
+// wave = 8 accumulator tiles) so that 64 VGPRs are free to PREFETCH the wave's share of the
+// C tile while the main loop runs: the read-modify-write epilogue of v1 (4 dependent
+// load->store round trips per tile, ~40 % of a K=256 tile's time) becomes subtract + store.
+// Waits are counted by hand: the C loads are issued in four 8-load pieces AFTER the LDS-DMA
+// of the next stage, so `s_waitcnt vmcnt(8)` retires the stage while the piece stays in
+// flight across the raw s_barrier (hipcc's __syncthreads would drain everything).
+// Register budget <= 168 (3 waves/SIMD): one workgroup per CU leaves a third wave slot per
+// SIMD and 87 KB of LDS for the panel kernels of the look-ahead stream.
+// ---------------------------------------------------------------------------
+template <int N_> struct ic { static constexpr int value = N_; };
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_gemm8(const double *__restrict__ A, size_t lda,
+                                                  const double *__restrict__ B, size_t ldb,
+                                                  double *__restrict__ C, size_t ldc, int M, int N, int K, int order)
+{
+    __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
+    int ti, tj;
+    if (MODE == 1) {
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
+    } else {
+        ti = blockIdx.x;
+        tj = blockIdx.y;
+    }
+    const int m0 = ti * GT, n0 = tj * GT;
+    if (MODE == 1 && n0 >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = w & 1, wn = w >> 1;
+    // a tile wholly inside the matrix takes the branch-free path; for SYRK the diagonal tiles
+    // are computed in full (their strictly-upper outputs land in the unused upper triangle)
+    const bool interior = (m0 + GT <= M) && (n0 + GT <= N);
+
+    // staging: waves 0-3 stream the A tile (m index), waves 4-7 the B tile (n index); 4 k-rows each
+    const int op = w >> 2;
+    const double *gsrc = (op ? B + n0 : A + m0) + 2 * lane;
+    const size_t gld = op ? ldb : lda;
+    const int krow0 = (w & 3) * 4;
+
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (K + GK - 1) / GK;
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kr = krow0 + q;
+            int kc = k0 + kr;
+            kc = kc < K ? kc : K - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(gsrc + (size_t)kc * gld),
+                (__attribute__((address_space(3))) void *)&smem[stage][op][kr][0], 16, 0, 0);
+        }
+    };
+
+    // this lane's corner of the C tile; element (tn, tm, i) = cbase[tm*16 + (tn*16 + 4 i) * ldc]
+    double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 32 + lq) * ldc;
+    double cv[2][4][4];
+    auto prefetch = [&](auto pc) {  // piece P: tn = P>>1, tm in {2(P&1), 2(P&1)+1}: 8 loads
+        constexpr int P = decltype(pc)::value;
+        constexpr int tn = P >> 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int tm = 2 * (P & 1) + h;
+                cv[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
+            }
+    };
+    auto compute = [&](int st, int klim) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kr = kk * 4 + lq;
+            const bool kv = kr < klim;
+            double af[2], bf[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double a = smem[st][1][kr][wn * 32 + t * 16 + lr];
+                af[t] = kv ? a : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double b = smem[st][0][kr][wm * 64 + t * 16 + lr];
+                bf[t] = kv ? b : 0.0;
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
+        }
+    };
+    // one k-step: retire stage kt (leaving WAITN younger loads in flight), barrier, start the
+    // DMA of stage kt+1, optionally issue C-prefetch piece P behind it, multiply stage kt
+    auto step = [&](int kt, auto wn_, auto pc) {
+        constexpr int WAITN = decltype(wn_)::value;
+        constexpr int P = decltype(pc)::value;
+        // lgkmcnt(0): every LDS read of the stage about to be overwritten has returned before
+        // any wave can start the DMA into it (WAR across the barrier)
+        if constexpr (WAITN == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * GK);
+        if constexpr (P >= 0) prefetch(ic<P>{});
+        compute(kt & 1, K - kt * GK);
+    };
+
+    issue(0, 0);
+    const bool pf = (MODE != 2) && interior;
+    int kt = 0;
+    if (pf && nk >= 5) {
+        step(0, ic<0>{}, ic<0>{});
+        step(1, ic<8>{}, ic<1>{});
+        step(2, ic<8>{}, ic<2>{});
+        step(3, ic<8>{}, ic<3>{});
+        step(4, ic<8>{}, ic<-1>{});
+        kt = 5;
+    } else if (pf) {
+        prefetch(ic<0>{}); prefetch(ic<1>{}); prefetch(ic<2>{}); prefetch(ic<3>{});
+    }
+#pragma unroll 1
+    for (; kt < nk; ++kt) step(kt, ic<0>{}, ic<-1>{});
+
+    if (interior) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double *p = cbase + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc;
+                    *p = (MODE == 2) ? acc[tn][tm][i] : cv[tn][tm][i] - acc[tn][tm][i];
+                }
+    } else {
+        // edge tile: loads from clamped (always valid) addresses, guarded stores
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            double ce[4][4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int n = n0 + wn * 32 + tn * 16 + lq + 4 * i, m = m0 + wm * 64 + tm * 16 + lr;
+                    n = n < N ? n : N - 1;
+                    m = m < M ? m : M - 1;
+                    if (MODE != 2) ce[tm][i] = C[(size_t)m + (size_t)n * ldc];
+                }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + wn * 32 + tn * 16 + lq + 4 * i, m = m0 + wm * 64 + tm * 16 + lr;
+                    if (m < M && n < N && (MODE != 1 || n <= m))
+                        C[(size_t)m + (size_t)n * ldc] = (MODE == 2) ? acc[tn][tm][i] : ce[tm][i] - acc[tn][tm][i];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GEMM NT v3: v2's wave layout and C prefetch with a 3-buffer LDS ring, DMA issued TWO
+// k-steps ahead.  A stage has two full k-steps (~8k cycles) to land, so the counted wait at
+// the top of a step does not stall on HBM / Infinity-Cache latency.  Issue order per step:
+// [DMA stage kt+2] [C piece kt]; the wait lets everything younger than stage kt stay in
+// flight (4 DMA + up to two 8-load pieces).  One workgroup per CU (110 KB LDS).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vm_lgkm0(int n)
+{
+    // immediates only; n is wave-uniform.  lgkmcnt(0): the buffer the next DMA overwrites was
+    // read in the previous step -- those LDS reads must have returned before any wave passes
+    // the barrier and starts that DMA.
+    if (n >= 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    else if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_gemm9(const double *__restrict__ A, size_t lda,
+                                                  const double *__restrict__ B, size_t ldb,
+                                                  double *__restrict__ C, size_t ldc, int M, int N, int K, int order)
+{
+    __shared__ __attribute__((aligned(16))) double smem[3][2][GK][GP];
+    int ti, tj;
+    if (MODE == 1) {
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
+    } else {
+        ti = blockIdx.x;
+        tj = blockIdx.y;
+    }
+    const int m0 = ti * GT, n0 = tj * GT;
+    if (MODE == 1 && n0 >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = w & 1, wn = w >> 1;
+    const bool interior = (m0 + GT <= M) && (n0 + GT <= N);
+
+    const int op = w >> 2;
+    const double *gsrc = (op ? B + n0 : A + m0) + 2 * lane;
+    const size_t gld = op ? ldb : lda;
+    const int krow0 = (w & 3) * 4;
+
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (K + GK - 1) / GK;
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kr = krow0 + q;
+            int kc = k0 + kr;
+            kc = kc < K ? kc : K - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(gsrc + (size_t)kc * gld),
+                (__attribute__((address_space(3))) void *)&smem[stage][op][kr][0], 16, 0, 0);
+        }
+    };
+
+    double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 32 + lq) * ldc;
+    double cv[2][4][4];
+    auto prefetch = [&](auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int tn = P >> 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tm = 2 * (P & 1) + h;
+                cv[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
+            }
+    };
+    auto compute = [&](int st, int klim) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kr = kk * 4 + lq;
+            const bool kv = kr < klim;
+            double af[2], bf[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double a = smem[st][1][kr][wn * 32 + t * 16 + lr];
+                af[t] = kv ? a : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double b = smem[st][0][kr][wm * 64 + t * 16 + lr];
+                bf[t] = kv ? b : 0.0;
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
+        }
+    };
+
+    const bool pf = (MODE != 2) && interior;
+    int st = 0, st2 = 2;  // buffer of stage kt, buffer of stage kt+2
+    // one k-step with compile-time wait count and prefetch piece (straight-line code: hipcc
+    // then keeps the prefetched C values in place instead of copying them at branch joins)
+    auto step = [&](int kt, auto wn_, auto pc) {
+        constexpr int WAITN = decltype(wn_)::value;
+        constexpr int P = decltype(pc)::value;
+        wait_vm_lgkm0(WAITN);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue(st2, (kt + 2) * GK);
+        if constexpr (P >= 0) prefetch(ic<P>{});
+        compute(st, K - kt * GK);
+        st = (st == 2) ? 0 : st + 1;
+        st2 = (st2 == 2) ? 0 : st2 + 1;
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, GK);
+    int kt = 0;
+    if (pf && nk >= 8) {
+        // younger than stage kt and allowed to stay in flight: DMA kt+1 (4) + the C pieces of
+        // steps kt-1 and kt-2 (8 each)
+        step(0, ic<4>{}, ic<0>{});
+        step(1, ic<12>{}, ic<1>{});
+        step(2, ic<20>{}, ic<2>{});
+        step(3, ic<20>{}, ic<3>{});
+        step(4, ic<20>{}, ic<-1>{});
+        step(5, ic<12>{}, ic<-1>{});
+        kt = 6;
+    } else if (pf) {
+        prefetch(ic<0>{}); prefetch(ic<1>{}); prefetch(ic<2>{}); prefetch(ic<3>{});
+        step(0, ic<0>{}, ic<-1>{});  // drains the C loads too (short-K path)
+        kt = 1;
+    }
+#pragma unroll 1
+    for (; kt + 1 < nk; ++kt) step(kt, ic<4>{}, ic<-1>{});
+    if (kt < nk) step(kt, ic<0>{}, ic<-1>{});
+
+    if (interior) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double *p = cbase + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc;
+                    *p = (MODE == 2) ? acc[tn][tm][i] : cv[tn][tm][i] - acc[tn][tm][i];
+                }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            double ce[4][4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int n = n0 + wn * 32 + tn * 16 + lq + 4 * i, m = m0 + wm * 64 + tm * 16 + lr;
+                    n = n < N ? n : N - 1;
+                    m = m < M ? m : M - 1;
+                    if (MODE != 2) ce[tm][i] = C[(size_t)m + (size_t)n * ldc];
+                }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + wn * 32 + tn * 16 + lq + 4 * i, m = m0 + wm * 64 + tm * 16 + lr;
+                    if (m < M && n < N && (MODE != 1 || n <= m))
+                        C[(size_t)m + (size_t)n * ldc] = (MODE == 2) ? acc[tn][tm][i] : ce[tm][i] - acc[tn][tm][i];
+                }
+        }
+    }
+}
 
 // Packed factors (Fpack) of an ALREADY factored diagonal block: -L tiles in fragment
 // order and the inverse of every 16x16 diagonal tile.  Used by solves against a given L.
@@ -465,12 +899,23 @@ __global__ __launch_bounds__(256) void k_probe_peak(double *sink, int iters)
     const int l = threadIdx.x;
     d4 c0 = d4{0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
     double a = 1.0 + 1e-9 * l, b = 1.0 - 1e-9 * l;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    // inline asm keeps the eight accumulators pinned in VGPRs (the builtin form makes hipcc
+    // shuffle them through AGPRs every iteration, which is not what we want to time)
+#define GPMI_MFMA_ASM(cc) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(cc) : "v"(a), "v"(b))
     for (int it = 0; it < iters; ++it) {
-        c0 = mfma(a, b, c0); c1 = mfma(a, b, c1); c2 = mfma(a, b, c2); c3 = mfma(a, b, c3);
-        c4 = mfma(a, b, c4); c5 = mfma(a, b, c5); c6 = mfma(a, b, c6); c7 = mfma(a, b, c7);
+        GPMI_MFMA_ASM(c0); GPMI_MFMA_ASM(c1); GPMI_MFMA_ASM(c2); GPMI_MFMA_ASM(c3);
+        GPMI_MFMA_ASM(c4); GPMI_MFMA_ASM(c5); GPMI_MFMA_ASM(c6); GPMI_MFMA_ASM(c7);
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#undef GPMI_MFMA_ASM
     d4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (s[0] + s[1] + s[2] + s[3] == 123.456) sink[0] = s[0];
+    if (l == 0) {  // shader clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+        sink[8 + 2 * blockIdx.x] = (double)(t1 - t0);
+        sink[9 + 2 * blockIdx.x] = (double)(r1 - r0);
+    }
 }
 
 }  // namespace
@@ -478,15 +923,32 @@ __global__ __launch_bounds__(256) void k_probe_peak(double *sink, int iters)
 // ---------------------------------------------------------------------------
 // host-side drivers
 // ---------------------------------------------------------------------------
+int g_syrk_order = 0;    // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
+int g_gemm_variant = 3;  // 0: v1 (4 waves, RMW epilogue), 1: v2 (8 waves, prefetched C)
+
 void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus)
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
+    if (g_gemm_variant == 2) {
+        if (accumulate_minus)
+            hipLaunchKernelGGL(k_gemm9<0>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
+        else
+            hipLaunchKernelGGL(k_gemm9<2>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
+        return;
+    }
+    if (g_gemm_variant == 1) {
+        if (accumulate_minus)
+            hipLaunchKernelGGL(k_gemm8<0>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
+        else
+            hipLaunchKernelGGL(k_gemm8<2>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
+        return;
+    }
     if (accumulate_minus)
-        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+        { if (g_gemm_variant == 3) hipLaunchKernelGGL((k_gemm_nt<0, 1>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); else hipLaunchKernelGGL((k_gemm_nt<0, 0>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); }
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+        { if (g_gemm_variant == 3) hipLaunchKernelGGL((k_gemm_nt<2, 1>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); else hipLaunchKernelGGL((k_gemm_nt<2, 0>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); }
 }
 
 static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
@@ -494,41 +956,101 @@ static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int T = (M + GT - 1) / GT;
-    const int ntiles = T * (T + 1) / 2;
-    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K);
+    const int ntiles = syrk_grid(T, g_syrk_order);
+    if (g_gemm_variant == 2) {
+        hipLaunchKernelGGL(k_gemm9<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+        return;
+    }
+    if (g_gemm_variant == 1) {
+        hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+        return;
+    }
+    if (g_gemm_variant == 3) hipLaunchKernelGGL((k_gemm_nt<1, 1>), dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+    else hipLaunchKernelGGL((k_gemm_nt<1, 0>), dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+}
+
+void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k)
+{
+    launch_syrk_lower(s, P, ldp, C, ldc, m, m, k);
 }
 
 int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int nfac, int *d_info,
                          double *Fpack_all)
 {
-    hipStream_t s = c->stream;
-    const int NB = GPMI_NB, NBO = c->nb_outer;
-    for (int k = 0; k < nfac; k += NB) {
-        const int kb = (nfac - k < NB) ? nfac - k : NB;
-        double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK : c->Fpack;
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), 512, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
-                           d_info, k);
-        const int r0 = k + kb;
-        if (r0 < M) {
-            const int nblk = (M - r0 + 63) / 64;
-            hipLaunchKernelGGL(k_trsm_panel, dim3(nblk), 256, 0, s, W + (size_t)k * ld, ld, r0, M, kb, Fp);
+    // Right-looking with one-block look-ahead.  Per outer block s of NBO columns:
+    //   Panel(s)  : [diag potrf, panel solve, in-block update] x (NBO/128)     -> panel stream
+    //   U1(s)     : update of the NEXT block's NBO columns (rect GEMM, K = NBO)  -> main stream
+    //   U2(s)     : SYRK of everything right of them (the bulk of the flops)    -> main stream
+    // Panel(s+1) needs only U1(s), so it runs on the high-priority panel stream while U2(s)
+    // fills the chip; U1(s+1) waits for Panel(s+1).  No data is shared between concurrent
+    // kernels: Panel(s+1) touches block s+1's columns, U2(s) reads block s and writes >= s+2.
+    // outer block width: K of the trailing update.  512 halves the C traffic and the number of
+    // epilogues once the trailing matrix is large; 256 keeps the panel phase short otherwise.
+    const int NBO = c->nb_outer > 0 ? c->nb_outer : (nfac >= 12288 ? 512 : 256);
+    const bool la = c->lookahead && c->pstream && nfac > NBO;
+    // with look-ahead the trailing updates may run on a CU-masked stream that leaves a few CUs
+    // free, so that the panel kernels (which fit nowhere next to two resident SYRK
+    // workgroups) are not starved by the thousands of queued trailing-update workgroups
+    const bool masked = la && c->cu_reserve > 0 && c->mstream;
+    hipStream_t sm = masked ? c->mstream : c->stream;
+    hipStream_t sp = la ? c->pstream : sm;
+    const int NB = GPMI_NB;
+    if (masked) {
+        hipEventRecord(c->evM, c->stream);
+        hipStreamWaitEvent(sm, c->evM, 0);
+    }
+    if (la) {
+        hipEventRecord(c->evU, sm);  // panel stream starts after everything already queued on main
+        hipStreamWaitEvent(sp, c->evU, 0);
+    }
+    for (int ko = 0; ko < nfac; ko += NBO) {
+        const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
+        // ---- Panel(s)
+        if (!la) kt_begin(c, 2, sm);
+        for (int k = ko; k < ke; k += NB) {
+            const int kb = (ke - k < NB) ? ke - k : NB;
+            double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK : c->Fpack;
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), 512, 0, sp, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
+                               d_info, k);
+            const int r0 = k + kb;
+            if (r0 < M)
+                hipLaunchKernelGGL(k_trsm_panel, dim3((M - r0 + 63) / 64), 256, 0, sp, W + (size_t)k * ld, ld,
+                                   r0, M, kb, Fp);
+            if (r0 < ke)  // rest of this outer block's columns: rows [r0, M) x cols [r0, ke), K = kb
+                launch_gemm_nt(sp, W + (size_t)r0 + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
+                               W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, ke - r0, kb, 1);
         }
-        const int ko = (k / NBO) * NBO;
-        const bool last_inner = ((r0 % NBO) == 0) || (r0 >= nfac);
-        if (!last_inner) {
-            int cend = ko + NBO;
-            if (cend > nfac) cend = nfac;
-            // rest of this outer block's columns: rows [r0, M) x cols [r0, cend), K = kb
-            launch_gemm_nt(s, W + (size_t)r0 + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
-                           W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, cend - r0, kb, 1);
-        } else if (r0 < M && r0 < ncol) {
-            const double mt = (double)(ncol - r0), extra = (double)(M - ncol);
-            kt_begin(c, 1);
-            launch_syrk_lower(s, W + (size_t)r0 + (size_t)ko * ld, ld, W + (size_t)r0 + (size_t)r0 * ld, ld,
-                              M - r0, ncol - r0, r0 - ko);
+        if (la) {
+            hipEventRecord(c->evP, sp);
+            hipStreamWaitEvent(sm, c->evP, 0);
+        } else {
+            kt_end(c, 2, 0.0, sm);
+        }
+        // ---- trailing updates with the whole outer block, K = ke - ko
+        const int r0 = ke;
+        if (r0 >= M || r0 >= ncol) continue;
+        const int K = ke - ko;
+        const double *P = W + (size_t)r0 + (size_t)ko * ld;
+        int n1 = 0;
+        if (la && ke < nfac) {
+            n1 = (nfac - ke < NBO) ? nfac - ke : NBO;  // columns of the next outer block
+            launch_gemm_nt(sm, P, ld, P, ld, W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, n1, K, 1);
+            hipEventRecord(c->evU, sm);
+            hipStreamWaitEvent(sp, c->evU, 0);
+        }
+        const int r1 = r0 + n1;
+        if (r1 < M && r1 < ncol) {
+            const double mt = (double)(ncol - r1), extra = (double)(M - ncol);
+            kt_begin(c, 1, sm);
+            launch_syrk_lower(sm, W + (size_t)r1 + (size_t)ko * ld, ld, W + (size_t)r1 + (size_t)r1 * ld, ld,
+                              M - r1, ncol - r1, K);
             // algorithmic flops: lower triangle (incl. diagonal) of the square part + extra rows
-            kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(r0 - ko));
+            kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)K, sm);
         }
+    }
+    if (masked) {
+        hipEventRecord(c->evM, sm);
+        hipStreamWaitEvent(c->stream, c->evM, 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "potrf launch failed: %s", hipGetErrorString(e));

@@ -46,7 +46,7 @@ struct KTimer {
     double work[3] = {0, 0, 0};
 };
 
-void kt_begin(gpmi_ctx *c, int cat)
+void kt_begin(gpmi_ctx *c, int cat, hipStream_t st)
 {
     if (!c->ktiming) return;
     KTimer *k = (KTimer *)c->ktimer;
@@ -57,19 +57,40 @@ void kt_begin(gpmi_ctx *c, int cat)
         k->a[cat].push_back(e0);
         k->b[cat].push_back(e1);
     }
-    hipEventRecord(k->a[cat][k->used[cat]], c->stream);
+    hipEventRecord(k->a[cat][k->used[cat]], st ? st : c->stream);
 }
 
-void kt_end(gpmi_ctx *c, int cat, double work)
+void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t st)
 {
     if (!c->ktiming) return;
     KTimer *k = (KTimer *)c->ktimer;
-    hipEventRecord(k->b[cat][k->used[cat]], c->stream);
+    hipEventRecord(k->b[cat][k->used[cat]], st ? st : c->stream);
     k->used[cat]++;
     k->work[cat] += work;
 }
 
 extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9);
+
+// (re)create the CU-masked trailing-update stream for the current cu_reserve / mode
+int ensure_mstream(gpmi_ctx *c)
+{
+    static_assert(sizeof(uint32_t) == 4, "");
+    if (c->cu_reserve <= 0) return 0;
+    if (c->mstream) return 0;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int ncu = prop.multiProcessorCount;
+    const int words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+    if (ncu % 32) mask[words - 1] = (1u << (ncu % 32)) - 1u;
+    const int nres = c->cu_reserve < ncu / 2 ? c->cu_reserve : ncu / 2;
+    for (int r = 0; r < nres; ++r) {
+        const int bit = c->cu_mask_mode == 1 ? r : (int)(((long long)r * ncu) / nres);
+        mask[bit / 32] &= ~(1u << (bit % 32));
+    }
+    HIPCHK(hipExtStreamCreateWithCUMask(&c->mstream, (uint32_t)words, mask.data()));
+    return 0;
+}
 
 // ---- context ---------------------------------------------------------------
 static int enter(gpmi_ctx *c)
@@ -104,9 +125,18 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
     if (!c) return gpmi_fail(GPMI_ENOMEM, "host allocation failed");
     c->device = device;
     c->pid = (int)getpid();
-    c->nb_outer = 256;
+    c->nb_outer = 0;  // auto
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, greatest));
+        HIPCHK(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evU, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
+        c->lookahead = 0;
+    }
     HIPCHK(hipMalloc((void **)&c->Fpack, GPMI_FPACK * sizeof(double)));
     HIPCHK(hipMalloc((void **)&c->d_info, 64));
     HIPCHK(hipMalloc((void **)&c->d_out, 64));
@@ -130,6 +160,15 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
             hipFree(c->stage[i]);
             hipEventDestroy(c->ev[i]);
         }
+        hipStreamSynchronize(c->pstream);
+        hipStreamDestroy(c->pstream);
+        if (c->mstream) {
+            hipStreamSynchronize(c->mstream);
+            hipStreamDestroy(c->mstream);
+        }
+        hipEventDestroy(c->evM);
+        hipEventDestroy(c->evP);
+        hipEventDestroy(c->evU);
         hipStreamDestroy(c->own_stream);
     }
     free(c);
@@ -155,9 +194,34 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     ENTER(c);
     if (!name) return gpmi_fail(GPMI_EARG, "option name is NULL");
     if (!strcmp(name, "nb_outer")) {
-        if (value == 0) value = 256;
-        if (value < GPMI_NB || value % GPMI_NB) return gpmi_fail(GPMI_EARG, "nb_outer must be a multiple of %d", GPMI_NB);
+        if (value != 0 && (value < GPMI_NB || value % GPMI_NB))
+            return gpmi_fail(GPMI_EARG, "nb_outer must be 0 (auto) or a multiple of %d", GPMI_NB);
         c->nb_outer = value;
+        return 0;
+    }
+    if (!strcmp(name, "cu_reserve") || !strcmp(name, "cu_mask_mode")) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->mstream) {
+            HIPCHK(hipStreamSynchronize(c->mstream));
+            HIPCHK(hipStreamDestroy(c->mstream));
+            c->mstream = nullptr;
+        }
+        if (!strcmp(name, "cu_reserve")) c->cu_reserve = value;
+        else c->cu_mask_mode = value;
+        return ensure_mstream(c);
+    }
+    if (!strcmp(name, "syrk_order")) {
+        extern int g_syrk_order;
+        g_syrk_order = value;
+        return 0;
+    }
+    if (!strcmp(name, "gemm_variant")) {
+        extern int g_gemm_variant;
+        g_gemm_variant = value;
+        return 0;
+    }
+    if (!strcmp(name, "lookahead")) {
+        c->lookahead = value != 0;
         return 0;
     }
     if (!strcmp(name, "timing")) {
@@ -770,6 +834,40 @@ extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
     return 0;
 }
 
+// Stand-alone trailing-update launch on synthetic data: C (m x m, lower) -= P P^T, P m x k.
+// `reps` back-to-back launches timed with HIP events; ms = average per launch.
+void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k);
+__global__ void k_fill(double *p, size_t n, double scale)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = i * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 29;
+        p[i] = scale * ((double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5);
+    }
+}
+extern "C" int gpmi_probe_syrk(gpmi_ctx *c, int m, int k, int reps, double *ms)
+{
+    ENTER(c);
+    if (m <= 0 || k <= 0 || reps <= 0 || !ms) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    if ((rc = reserve_ws(c, m, m))) return rc;
+    const size_t ld = (size_t)c->ld;
+    double *P;
+    if ((rc = stage_buf(c, 3, ld * (size_t)(k + 1) * sizeof(double), &P))) return rc;
+    hipLaunchKernelGGL(k_fill, dim3(2048), 256, 0, c->stream, c->W, ld * (size_t)m, 1.0);
+    hipLaunchKernelGGL(k_fill, dim3(2048), 256, 0, c->stream, P, ld * (size_t)k, 1e-3);
+    launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k);
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    for (int r = 0; r < reps; ++r) launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k);
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+    *ms = t / reps;
+    return 0;
+}
+
 extern "C" int gpmi_probe_mfma(gpmi_ctx *c, const double *A64, const double *B64, double *out256)
 {
     ENTER(c);
@@ -786,13 +884,13 @@ extern "C" int gpmi_probe_mfma(gpmi_ctx *c, const double *A64, const double *B64
     return 0;
 }
 
-extern "C" int gpmi_probe_mfma_peak(gpmi_ctx *c, int iters, double *tflops)
+extern "C" int gpmi_probe_mfma_peak(gpmi_ctx *c, int iters, double *tflops, double *clock_mhz)
 {
     ENTER(c);
     if (iters <= 0 || !tflops) return gpmi_fail(GPMI_EARG, "bad argument");
     double *d;
     int rc, blocks = 0, threads = 0;
-    if ((rc = stage_buf(c, 0, 64, &d))) return rc;
+    if ((rc = stage_buf(c, 0, (8 + 2 * 1024) * sizeof(double), &d))) return rc;
     launch_probe_peak(c->stream, d, 16, &blocks, &threads);  // warm-up
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     launch_probe_peak(c->stream, d, iters, &blocks, &threads);
@@ -802,5 +900,15 @@ extern "C" int gpmi_probe_mfma_peak(gpmi_ctx *c, int iters, double *tflops)
     HIPCHK(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     const double flops = (double)blocks * (threads / 64) * (double)iters * 8.0 * 2048.0;
     *tflops = flops / (ms * 1e-3) / 1e12;
+    if (clock_mhz) {
+        std::vector<double> h(8 + 2 * (size_t)blocks);
+        HIPCHK(hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double cyc = 0.0, real = 0.0;
+        for (int b = 0; b < blocks; ++b) {
+            cyc += h[8 + 2 * b];
+            real += h[9 + 2 * b];
+        }
+        *clock_mhz = real > 0.0 ? cyc / real * 100.0 : 0.0;
+    }
     return 0;
 }

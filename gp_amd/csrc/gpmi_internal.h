@@ -34,6 +34,13 @@ struct gpmi_ctx {
     double *stage[4];
     size_t stage_bytes[4];
     int nb_outer;            // outer panel width (multiple of GPMI_NB)
+    int lookahead;           // factor the next panel on pstream while the trailing update runs
+    hipStream_t pstream;     // high-priority panel stream
+    hipStream_t mstream;     // CU-masked stream for the trailing updates (leaves cu_reserve CUs free)
+    int cu_reserve;          // CUs kept out of the trailing-update stream's mask (0 = no masking)
+    int cu_mask_mode;        // 0: reserve CU bits strided over the mask, 1: the lowest bits
+    hipEvent_t evM;
+    hipEvent_t evP, evU;     // panel done / next-panel columns updated
     int timing;
     hipEvent_t ev[4];
     double last_ms[3];
@@ -44,8 +51,9 @@ struct gpmi_ctx {
 };
 
 // event-pair recorder; begin/end bracket one launch on the context's stream
-void kt_begin(gpmi_ctx *c, int cat);
-void kt_end(gpmi_ctx *c, int cat, double work);
+void kt_begin(gpmi_ctx *c, int cat, hipStream_t s = nullptr);
+void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t s = nullptr);
+int ensure_mstream(gpmi_ctx *c);
 
 // ---- error plumbing -------------------------------------------------------
 int gpmi_fail(int code, const char *fmt, ...);

@@ -189,12 +189,17 @@ int gpmi_last_timing(gpmi_ctx *ctx, double *ms3);
  * out9[3*cat + 0..2] = launches, total ms, total work since the last reset. */
 int gpmi_kernel_timing(gpmi_ctx *ctx, int reset, double *out9);
 
+/* Stand-alone trailing-update (SYRK, lower) launch on synthetic data, C(m x m) -= P P^T with
+ * P m x k: average ms per launch over `reps` back-to-back launches (HIP events). */
+int gpmi_probe_syrk(gpmi_ctx *ctx, int m, int k, int reps, double *ms);
+
 /* MFMA f64 fragment-layout probe: D = A(16x4) * B(4x16) on one wave with the
  * library's fragment conventions; out256 row-major D[i][j].  Host buffers. */
 int gpmi_probe_mfma(gpmi_ctx *ctx, const double *A64, const double *B64, double *out256);
-/* Back-to-back v_mfma_f64_16x16x4_f64 issue-rate microbenchmark: returns
- * achieved TFLOP/s over the whole chip. */
-int gpmi_probe_mfma_peak(gpmi_ctx *ctx, int iters, double *tflops);
+/* Back-to-back v_mfma_f64_16x16x4_f64 issue-rate microbenchmark: achieved TFLOP/s over
+ * the whole chip and (nullable) the shader clock held meanwhile, from
+ * d(s_memtime)/d(s_memrealtime). */
+int gpmi_probe_mfma_peak(gpmi_ctx *ctx, int iters, double *tflops, double *clock_mhz);
 
 #ifdef __cplusplus
 }
