@@ -44,146 +44,123 @@ __device__ __host__ constexpr int fp_l(int jb, int kb) { return jb * (jb - 1) / 
 __device__ __host__ constexpr int fp_inv(int jb) { return 28 + jb; }
 
 
-// Cholesky of a 16x16 SPD tile held in LDS as [row][col] (lower triangle used) and the
-// inverse of its factor.  One wave; every lane keeps matrix row lane&15 in registers (four
-// redundant copies), pivots and multipliers travel through v_readlane.  Out: s_d16 = L16
-// (upper zeroed), s_inv = L16^-1 in MFMA A-operand order
-// s_inv[kg*64 + l] = Linv[l&15][(l>>4) + 4*kg].  Returns 0 or 1 + index of the first
-// non-positive pivot.  Kept out of line so the 8 call sites share one register allocation.
-__device__ __noinline__ int factor16(double (*s_d16)[17], double *s_inv, int lane)
-{
-    const int lr = lane & 15, lq = lane >> 4;
-    double row[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) row[c] = s_d16[lr][c];
-    int bad = 0;
-    double dinv[16];  // 1 / L_jj, wave-uniform
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        double d = readlane64(row[j], j);
-        if (!(d > 0.0)) {
-            if (!bad) bad = j + 1;
-            d = 1.0;
-        }
-        // s = sqrt(d) through one rsqrt and a Newton correction (keeps the 128-pivot critical
-        // path short: no fp64 sqrt + divide chain); multipliers use the reciprocal
-        const double ri = rsqrt(d);
-        double s = d * ri;
-        s = fma(0.5 * ri, fma(-s, s, d), s);
-        const double inv = fma(ri, fma(-s, ri, 1.0), ri);  // 1/s refined
-        dinv[j] = inv;
-        double cj = row[j] * inv;
-        cj = (lr == j) ? s : cj;
-        row[j] = cj;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-            const double lc = readlane64(cj, c);
-            row[c] = fma(-cj, lc, row[c]);
-        }
-    }
-    // inverse: lane c (= lr) solves column c of L16 X = I
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        double s = (r == lr) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) s = fma(-readlane64(row[k], r), x[k], s);
-        x[r] = s * dinv[r];
-    }
-    if (lq == 0) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s_d16[lr][c] = (c <= lr) ? row[c] : 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s_inv[(lr >> 2) * 64 + j + 16 * (lr & 3)] = x[j];
-    }
-    return bad;
-}
+#include "factor16.h"
 
 // ---------------------------------------------------------------------------
-// Diagonal block.  8 waves; wave w owns block-row w (16 matrix rows) as tiles
-// T[jb], jb <= w.  Right-looking over the 8 block columns.
+// Diagonal block (<= 128 x 128).  One workgroup of 5 waves:
+//   waves 0-3 "tile waves": wave w owns block-rows w and 7-w (9 register tiles, balanced),
+//             held transposed in the MFMA accumulator layout T[jb][reg] = A[row][jb*16+col];
+//             fully unrolled over the 8 block columns (compile-time tile indices);
+//   wave 4    "factor wave": runs the sequential 16x16 factor + inverse (factor16) for every
+//             block column out of LDS; it holds no tiles, so the register-hungry broadcast
+//             code exists once and never forces tile copies at control-flow joins.
+// Right-looking over the block columns; three workgroup barriers per column.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_potrf_diag(double *__restrict__ A, size_t lda, int nb_act,
+__global__ __launch_bounds__(320) void k_potrf_diag(double *__restrict__ A, size_t lda, int nb_act,
                                                     double *__restrict__ Fpack, int *info, int col0)
 {
     __shared__ double s_pub[2][8][256];
-    __shared__ double s_inv[256];
+    __shared__ double s_inv[8][256];  // L16^-1 of every block column (kept: written to Fpack at the end)
     __shared__ double s_d16[16][17];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
+    // No global store is issued inside the column loop: a __syncthreads() behind a store waits
+    // for its acknowledgement (~us).  The packed factors go out after the loop -- the -L tiles
+    // ARE the final tile registers, the inverses wait in LDS.
 
-    d4 T[8];
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        T[jb] = d4{0.0, 0.0, 0.0, 0.0};
-        if (jb <= w) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = jb * 16 + lq + 4 * i, row = w * 16 + lr;
-                const int rr = row > col ? row : col, cc = row > col ? col : row;
-                T[jb][i] = (rr < nb_act) ? A[(size_t)rr + (size_t)cc * lda] : (row == col ? 1.0 : 0.0);
-            }
+    if (w == 4) {
+#pragma unroll 1
+        for (int kb = 0; kb < 8; ++kb) {
+            __syncthreads();  // B1: the owner's diagonal tile is in s_d16
+            const int bad = factor16(s_d16, s_inv[kb], lane);
+            if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
+            __syncthreads();  // B2: L16 in s_d16, L16^-1 in s_inv
+            __syncthreads();  // B3: -X tiles published
         }
+        return;
+    }
+
+    const int ra = w, rb = 7 - w;  // the two block-rows of this wave, ra < rb
+    d4 TA[8], TB[8];
+#define GPMI_LOAD_ROW(T, br)                                                                           \
+    _Pragma("unroll") for (int jb = 0; jb < 8; ++jb) {                                                 \
+        T[jb] = d4{0.0, 0.0, 0.0, 0.0};                                                                \
+        if (jb <= (br)) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
+                const int rr = row > col ? row : col, cc = row > col ? col : row;                      \
+                T[jb][i] = (rr < nb_act) ? A[(size_t)rr + (size_t)cc * lda] : (row == col ? 1.0 : 0.0); \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    GPMI_LOAD_ROW(TA, ra)
+    GPMI_LOAD_ROW(TB, rb)
+
+#define GPMI_SOLVE_ROW(T, br, X)                                                                       \
+    if ((br) == kb) {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) T[kb][i] = s_d16[lr][lq + 4 * i];                \
+    } else if ((br) > kb) {                                                                            \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
+            X = mfma(s_inv[kb][kg * 64 + lane], T[kb][kg], X);                                         \
+        T[kb] = X;                                                                                     \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) s_pub[kb & 1][br][kg * 64 + lane] = -X[kg];   \
+    }
+#define GPMI_UPDATE_ROW(T, br, X)                                                                      \
+    _Pragma("unroll") for (int jb = kb + 1; jb < 8; ++jb) {                                            \
+        if (jb <= (br)) {                                                                              \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                           \
+                T[jb] = mfma(s_pub[kb & 1][jb][kg * 64 + lane], X[kg], T[jb]);                         \
+        }                                                                                              \
     }
 
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        // (a1) owner publishes its updated diagonal tile in matrix order [row][col]
-        // (a2) then factors it and inverts the factor (LDS in, LDS out).  Same wave: LDS
-        // operations of one wave complete in order, no workgroup barrier needed in between.
-        if (w == kb) {
+        // (a) the owner hands its updated diagonal tile to the factor wave in matrix order
+        if (ra == kb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = T[kb][i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int bad = factor16(s_d16, s_inv, lane);
-            if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
+            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TA[kb][i];
+        } else if (rb == kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TB[kb][i];
         }
-        __syncthreads();
-        // (a3) owner reloads L16 in tile layout; (b) rows below: X = Linv16 * T[kb], publish -X
-        if (w == kb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) T[kb][i] = s_d16[lr][lq + 4 * i];
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg)
-                Fpack[(size_t)fp_inv(kb) * 256 + kg * 64 + lane] = s_inv[kg * 64 + lane];
-        } else if (w > kb) {
-            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) acc = mfma(s_inv[kg * 64 + lane], T[kb][kg], acc);
-            T[kb] = acc;
-            const int slot = w * (w - 1) / 2 + kb;
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                s_pub[kb & 1][w][kg * 64 + lane] = -acc[kg];
-                Fpack[(size_t)slot * 256 + kg * 64 + lane] = -acc[kg];
-            }
-        }
-        __syncthreads();
-        // (c) trailing tiles of this block-row: T[jb] -= L[jb][kb] * X_kb
-        if (w > kb) {
-#pragma unroll
-            for (int jb = kb + 1; jb < 8; ++jb) {
-                if (jb <= w) {
-#pragma unroll
-                    for (int kg = 0; kg < 4; ++kg)
-                        T[jb] = mfma(s_pub[kb & 1][jb][kg * 64 + lane], T[kb][kg], T[jb]);
-                }
-            }
-        }
+        __syncthreads();  // B1
+        __syncthreads();  // B2: factor wave done
+        // (a3) the owner reloads L16 in tile layout; (b) rows below: X = Linv16 * T[kb], publish -X
+        d4 XA = d4{0.0, 0.0, 0.0, 0.0}, XB = XA;
+        GPMI_SOLVE_ROW(TA, ra, XA)
+        GPMI_SOLVE_ROW(TB, rb, XB)
+        __syncthreads();  // B3
+        // (c) trailing tiles of both block-rows: T[jb] -= L[jb][kb] * X_kb
+        if (ra > kb) { GPMI_UPDATE_ROW(TA, ra, XA) }
+        if (rb > kb) { GPMI_UPDATE_ROW(TB, rb, XB) }
     }
 
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        if (jb <= w) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = jb * 16 + lq + 4 * i, row = w * 16 + lr;
-                if (row < nb_act && col <= row) A[(size_t)row + (size_t)col * lda] = T[jb][i];
-            }
-        }
+#define GPMI_STORE_ROW(T, br)                                                                          \
+    _Pragma("unroll") for (int jb = 0; jb < 8; ++jb) {                                                 \
+        if (jb <= (br)) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
+                if (row < nb_act && col <= row) A[(size_t)row + (size_t)col * lda] = T[jb][i];         \
+            }                                                                                          \
+            if (jb < (br)) {                                                                           \
+                _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                       \
+                    Fpack[(size_t)((br) * ((br) - 1) / 2 + jb) * 256 + kg * 64 + lane] = -T[jb][kg];   \
+            }                                                                                          \
+        }                                                                                              \
     }
+    GPMI_STORE_ROW(TA, ra)
+    GPMI_STORE_ROW(TB, rb)
+    // the two inverses this wave's block-rows belong to
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+        Fpack[(size_t)fp_inv(ra) * 256 + kg * 64 + lane] = s_inv[ra][kg * 64 + lane];
+        Fpack[(size_t)fp_inv(rb) * 256 + kg * 64 + lane] = s_inv[rb][kg * 64 + lane];
+    }
+#undef GPMI_LOAD_ROW
+#undef GPMI_SOLVE_ROW
+#undef GPMI_UPDATE_ROW
+#undef GPMI_STORE_ROW
 }
 
 // ---------------------------------------------------------------------------
@@ -296,12 +273,32 @@ __host__ inline int syrk_grid(int T, int order)
     return ((ns + 7) / 8) * 8 * ST * ST;
 }
 
-template <int MODE, int EPI>
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
                                                  const double *__restrict__ B, size_t ldb,
-                                                 double *__restrict__ C, size_t ldc, int M, int N, int K, int order)
+                                                 double *__restrict__ C, size_t ldc, int M, int N, int K, int order,
+                                                 int stagger)
 {
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
+    // Two workgroups share a CU and its matrix pipes.  All tiles cost the same, so workgroups
+    // that start together stay in lock-step: both reach their memory-bound epilogue at the
+    // same time and the pipes idle.  Delaying the second-dispatched workgroup of each CU once,
+    // by about one epilogue, puts the pair in anti-phase for the rest of the launch: one
+    // streams its C tile while the other has the pipes to itself.
+    // stagger = (mode << 16) | sleeps; mode 1: blocks 256..511 (second dispatch round),
+    // mode 2: odd hardware wave slot of wave 0 (HW_REG_HW_ID[3:0]).
+    if (stagger && blockIdx.x < 512) {
+        bool late = false;
+        if ((stagger >> 16) == 1) late = blockIdx.x >= 256;
+        else {
+            if (threadIdx.x == 0) smem[0][0][0][0] = (double)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1);
+            __syncthreads();
+            late = smem[0][0][0][0] != 0.0;
+            __syncthreads();
+        }
+        if (late)
+            for (int i = 0; i < (stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     int ti, tj;
     if (MODE == 1) {
         if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
@@ -340,109 +337,128 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
                 (__attribute__((address_space(3))) void *)&smem[stage][op][kr][0], 16, 0, 0);
         }
     };
-
-    auto compute = [&](int st, int klim) {
+    // Fragments of sub-step kk+1 are requested before the 16 MFMAs of sub-step kk are issued
+    // (two register sets), so the LDS latency sits under ~1k cycles of matrix work.  MASK
+    // (zeroing of columns past K) is compiled only into the last, possibly partial, k-step:
+    // a select on a just-loaded fragment forces the wait in front of the MFMAs.
+    auto ldfrag = [&](auto mk, int st, int kk, int klim, double (&af)[4], double (&bf)[4]) {
+        constexpr bool MASK = decltype(mk)::value != 0;
+        const int kr = kk * 4 + lq;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int kr = kk * 4 + lq;
+        for (int t = 0; t < 4; ++t) {
+            af[t] = smem[st][1][kr][wn * 64 + t * 16 + lr];
+            bf[t] = smem[st][0][kr][wm * 64 + t * 16 + lr];
+        }
+        if constexpr (MASK) {
             const bool kv = kr < klim;
-            double af[4], bf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const double a = smem[st][1][kr][wn * 64 + t * 16 + lr];
-                const double b = smem[st][0][kr][wm * 64 + t * 16 + lr];
-                af[t] = kv ? a : 0.0;
-                bf[t] = kv ? b : 0.0;
+                af[t] = kv ? af[t] : 0.0;
+                bf[t] = kv ? bf[t] : 0.0;
             }
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
         }
+    };
+    auto mm16 = [&](const double (&af)[4], const double (&bf)[4]) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
+    };
+    auto compute = [&](auto mk, int st, int klim) {
+        double a0[4], b0[4], a1[4], b1[4];
+        ldfrag(mk, st, 0, klim, a0, b0);
+        ldfrag(mk, st, 1, klim, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm16(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(mk, st, 2, klim, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm16(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(mk, st, 3, klim, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm16(a0, b0);
+        mm16(a1, b1);
     };
 
     issue(0, 0);
-    const int nloop = (EPI == 1) ? nk - 1 : nk;
-    for (int kt = 0; kt < nloop; ++kt) {
+#pragma unroll 1
+    for (int kt = 0; kt < nk - 1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * GK);
-        compute(kt & 1, K - kt * GK);
+        issue((kt + 1) & 1, (kt + 1) * GK);
+        compute(ic<0>{}, kt & 1, GK);
     }
 
-    if (EPI == 1) {
-        // Last k-step peeled.  For a tile wholly inside the matrix the first half of the C
-        // tile (32 loads per lane, uniform offsets from one base) is issued under that step --
-        // the staging loads are all retired by then -- and the second half right after the
-        // first half's stores: one memory round trip is exposed per tile instead of four.
-        const bool interior = (m0 + GT <= M) && (n0 + GT <= N);
-        double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 64 + lq) * ldc;
-        double ch[2][4][4];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (MODE != 2 && interior) {
+    // Last k-step peeled.  For a tile wholly inside the matrix the first half of the C tile
+    // (32 loads per lane, uniform offsets from one base) is issued under that step -- the
+    // staging loads are all retired by then -- and the second half right after the first
+    // half's stores: one memory round trip is exposed per tile instead of four.  For SYRK the
+    // diagonal tiles are computed in full (their strictly-upper outputs land in the unused
+    // upper triangle of the workspace).
+    const bool interior = (m0 + GT <= M) && (n0 + GT <= N);
+    double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 64 + lq) * ldc;
+    double ch[2][4][4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (MODE != 2 && interior) {
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
+            for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ch[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
-        }
-        compute((nk - 1) & 1, K - (nk - 1) * GK);
-        if (interior) {
+                for (int i = 0; i < 4; ++i) ch[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
+    }
+    compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK);
+    if (interior) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc] =
+                        (MODE == 2) ? acc[tn][tm][i] : ch[tn][tm][i] - acc[tn][tm][i];
+        if (MODE != 2) {
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc] =
-                            (MODE == 2) ? acc[tn][tm][i] : ch[tn][tm][i] - acc[tn][tm][i];
-            if (MODE != 2) {
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            ch[tn][tm][i] = cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc];
-            }
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc] =
-                            (MODE == 2) ? acc[tn + 2][tm][i] : ch[tn][tm][i] - acc[tn + 2][tm][i];
-            return;
+                        ch[tn][tm][i] = cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc];
         }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc] =
+                        (MODE == 2) ? acc[tn + 2][tm][i] : ch[tn][tm][i] - acc[tn + 2][tm][i];
+        return;
     }
 
-    // epilogue: per tn, 16 unconditional loads (masked elements read the tile origin, which
-    // is always valid) issued back to back, then the guarded stores
-    double *const csafe = C + (size_t)m0 + (size_t)n0 * ldc;
+    // edge tile: per tn, 16 loads from clamped (always valid) addresses, then guarded stores
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
-        double *p[4][4];
-        bool ok[4][4];
-        double cv[4][4];
+        double ce[4][4];
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 64 + tn * 16 + lq + 4 * i;
-                const int m = m0 + wm * 64 + tm * 16 + lr;
-                ok[tm][i] = m < M && n < N && (MODE != 1 || n <= m);
-                p[tm][i] = ok[tm][i] ? C + (size_t)m + (size_t)n * ldc : csafe;
-                if (MODE != 2) cv[tm][i] = *p[tm][i];
+                int n = n0 + wn * 64 + tn * 16 + lq + 4 * i, m = m0 + wm * 64 + tm * 16 + lr;
+                n = n < N ? n : N - 1;
+                m = m < M ? m : M - 1;
+                if (MODE != 2) ce[tm][i] = C[(size_t)m + (size_t)n * ldc];
             }
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const double v = (MODE == 2) ? acc[tn][tm][i] : cv[tm][i] - acc[tn][tm][i];
-                if (ok[tm][i]) *p[tm][i] = v;
+                const int n = n0 + wn * 64 + tn * 16 + lq + 4 * i, m = m0 + wm * 64 + tm * 16 + lr;
+                if (m < M && n < N && (MODE != 1 || n <= m))
+                    C[(size_t)m + (size_t)n * ldc] = (MODE == 2) ? acc[tn][tm][i] : ce[tm][i] - acc[tn][tm][i];
             }
     }
 }
@@ -459,8 +475,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
 // Register budget <= 168 (3 waves/SIMD): one workgroup per CU leaves a third wave slot per
 // SIMD and 87 KB of LDS for the panel kernels of the look-ahead stream.
 // ---------------------------------------------------------------------------
-template <int N_> struct ic { static constexpr int value = N_; };
-
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const double *__restrict__ A, size_t lda,
                                                   const double *__restrict__ B, size_t ldb,
@@ -924,7 +938,8 @@ __global__ __launch_bounds__(256) void k_probe_peak(double *sink, int iters)
 // host-side drivers
 // ---------------------------------------------------------------------------
 int g_syrk_order = 0;    // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
-int g_gemm_variant = 3;  // 0: v1 (4 waves, RMW epilogue), 1: v2 (8 waves, prefetched C)
+int g_gemm_variant = 3;
+int g_stagger = (2 << 16) | 4;       // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup  // 0: v1 (4 waves, RMW epilogue), 1: v2 (8 waves, prefetched C)
 
 void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus)
@@ -946,9 +961,9 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
         return;
     }
     if (accumulate_minus)
-        { if (g_gemm_variant == 3) hipLaunchKernelGGL((k_gemm_nt<0, 1>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); else hipLaunchKernelGGL((k_gemm_nt<0, 0>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); }
+        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0);
     else
-        { if (g_gemm_variant == 3) hipLaunchKernelGGL((k_gemm_nt<2, 1>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); else hipLaunchKernelGGL((k_gemm_nt<2, 0>), grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0); }
+        hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0);
 }
 
 static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
@@ -965,8 +980,8 @@ static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
         hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
         return;
     }
-    if (g_gemm_variant == 3) hipLaunchKernelGGL((k_gemm_nt<1, 1>), dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
-    else hipLaunchKernelGGL((k_gemm_nt<1, 0>), dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order,
+                       ntiles >= 1024 ? g_stagger : 0);  // only when every CU holds two workgroups for many rounds
 }
 
 void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k)
@@ -987,7 +1002,9 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     // outer block width: K of the trailing update.  512 halves the C traffic and the number of
     // epilogues once the trailing matrix is large; 256 keeps the panel phase short otherwise.
     const int NBO = c->nb_outer > 0 ? c->nb_outer : (nfac >= 12288 ? 512 : 256);
-    const bool la = c->lookahead && c->pstream && nfac > NBO;
+    // look-ahead pays once the trailing update dominates (measured: N >= ~12k on MI355X)
+    const bool want_la = c->lookahead > 0 || (c->lookahead < 0 && nfac >= 12288);
+    const bool la = want_la && c->pstream && nfac > NBO;
     // with look-ahead the trailing updates may run on a CU-masked stream that leaves a few CUs
     // free, so that the panel kernels (which fit nowhere next to two resident SYRK
     // workgroups) are not starved by the thousands of queued trailing-update workgroups
@@ -1010,7 +1027,7 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
         for (int k = ko; k < ke; k += NB) {
             const int kb = (ke - k < NB) ? ke - k : NB;
             double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK : c->Fpack;
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), 512, 0, sp, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, sp, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
                                d_info, k);
             const int r0 = k + kb;
             if (r0 < M)

@@ -135,12 +135,18 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
         HIPCHK(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evU, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
-        c->lookahead = 0;
+        c->lookahead = -1;  // auto: on for large factorisations (see launch_potrf_partial)
+        c->cu_reserve = 8;
+        c->cu_mask_mode = 1;
     }
     HIPCHK(hipMalloc((void **)&c->Fpack, GPMI_FPACK * sizeof(double)));
     HIPCHK(hipMalloc((void **)&c->d_info, 64));
     HIPCHK(hipMalloc((void **)&c->d_out, 64));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    {
+        int rc = ensure_mstream(c);
+        if (rc) return rc;
+    }
     *out = c;
     return 0;
 }
@@ -210,6 +216,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         else c->cu_mask_mode = value;
         return ensure_mstream(c);
     }
+    if (!strcmp(name, "stagger")) {
+        extern int g_stagger;
+        g_stagger = value;
+        return 0;
+    }
     if (!strcmp(name, "syrk_order")) {
         extern int g_syrk_order;
         g_syrk_order = value;
@@ -220,8 +231,8 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         g_gemm_variant = value;
         return 0;
     }
-    if (!strcmp(name, "lookahead")) {
-        c->lookahead = value != 0;
+    if (!strcmp(name, "lookahead")) {  // 0 off, 1 on, -1 auto
+        c->lookahead = value;
         return 0;
     }
     if (!strcmp(name, "timing")) {
