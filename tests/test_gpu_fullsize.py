@@ -1,0 +1,147 @@
+"""GPU: BASELINE.json's full sizes.  The oracle cannot finish N=16384 in seconds, so the full-size
+checks use size-independent properties (scaling identity, determinism, L L^T residual on
+sampled rows, log-det / solve recomputed from the factor) plus LAPACK (scipy) and the oracle at
+the largest sizes they finish in seconds.  torch.linalg / rocBLAS appear here ONLY as
+cross-checks of results, never in the product path."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOGML_RTOL = 1e-8
+
+
+def _dev_inputs(n, D):
+    import torch
+    from gp_amd.synth import synth
+    X, y = synth(n, D)
+    dev = torch.device("cuda:0")
+    dX = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)  # (D, n) row-major == n x D column-major
+    dy = torch.from_numpy(y).to(dev)
+    return X, y, dX, dy
+
+
+def test_c2_n4096_vs_oracle_and_lapack(ctx, orc):
+    # config c2: N=4096, D=3
+    import scipy.linalg as sla
+    from gp_amd.synth import synth
+    X, y = synth(4096, 3)
+    got = ctx.logml(X, y, 1.0, [0.3], 0.1)
+    want = orc.logml(X, y, 1.0, 0.3, 0.1)
+    assert want[3] == 0 and abs(got[0] - want[0]) <= LOGML_RTOL * abs(want[0])
+    K = orc.cov_exp_quad(X, 1.0, 0.3) + 0.01 * np.eye(4096)
+    L = sla.cholesky(K, lower=True)
+    z = sla.solve_triangular(L, y, lower=True)
+    lap = -0.5 * z @ z - np.log(np.diag(L)).sum() - 2048 * math.log(2 * math.pi)
+    assert abs(got[0] - lap) <= LOGML_RTOL * abs(lap)
+    # the factor itself
+    Lg = ctx.potrf(K)
+    assert np.max(np.abs(Lg - L)) <= 1e-10
+    assert np.linalg.norm(Lg @ Lg.T - K) / np.linalg.norm(K) <= 1e-13 * math.sqrt(4096)
+
+
+def test_c3_n16384_properties(ctx):
+    # config c3: N=16384, D=3 -- the bench workload
+    import torch
+    n, D = 16384, 3
+    X, y, dX, dy = _dev_inputs(n, D)
+    dev = dX.device
+    out = torch.zeros((4, 3), dtype=torch.float64, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx.logml_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), 1.0, [0.3], 0.1, 0.0, out[0].data_ptr(), info[0:].data_ptr())
+    ctx.logml_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), 1.0, [0.3], 0.1, 0.0, out[1].data_ptr(), info[1:].data_ptr())
+    # scaling identity: logml(X, c y; c alpha, rho, c sigma) = logml(X, y; alpha, rho, sigma) - N log c
+    c = 1.7
+    dyc = dy * c
+    ctx.logml_dev(dX.data_ptr(), n, n, D, dyc.data_ptr(), c * 1.0, [0.3], c * 0.1, 0.0, out[2].data_ptr(), info[2:].data_ptr())
+    ctx.sync()
+    o = out.cpu().numpy(); inf = info.cpu().numpy()
+    assert np.all(inf[:3] == 0) and np.all(np.isfinite(o[:3]))
+    assert o[0, 0] == o[1, 0] and o[0, 1] == o[1, 1]  # deterministic: bit-identical repeat
+    assert abs(o[2, 0] - (o[0, 0] - n * math.log(c))) <= LOGML_RTOL * abs(o[0, 0])
+    assert abs(o[2, 2] - o[0, 2]) <= 1e-9 * abs(o[0, 2])  # z'z is scale invariant
+
+    # covariance build: sampled entries against the closed form (<= 4 ulp of alpha^2)
+    K = torch.empty((n, n), dtype=torch.float64, device=dev)  # column-major n x n == symmetric
+    ctx.se_cov_dev(dX.data_ptr(), n, n, 0, n, n, D, 1.0, [0.3], 0.01, 0, K.data_ptr(), n)
+    ctx.sync()
+    rng = np.random.default_rng(0)
+    ii = rng.integers(0, n, 4000); jj = rng.integers(0, n, 4000)
+    kv = K[torch.from_numpy(jj).to(dev), torch.from_numpy(ii).to(dev)].cpu().numpy()  # K[col j][row i]
+    d2 = ((X[ii] - X[jj]) ** 2).sum(1)
+    ref = np.exp(-0.5 * d2 / 0.09) + np.where(ii == jj, 0.01, 0.0)
+    assert np.max(np.abs(kv - ref)) <= 4 * np.finfo(float).eps
+
+    # factor in place; L L^T residual on sampled rows; log-det and quadratic form recomputed from L
+    Kc = K.clone()
+    ctx.potrf_dev(K.data_ptr(), n, n, info[3:].data_ptr())
+    ctx.sync()
+    assert int(info[3].item()) == 0
+    Lt = K  # memory holds L column-major == L^T as a row-major torch matrix (upper triangular view)
+    assert float(torch.tril(Lt, -1).abs().max().item()) == 0.0  # strict upper of L zeroed
+    rows = torch.from_numpy(rng.integers(0, n, 48)).to(dev)
+    # (L L^T)[r, :] = L[r, :] @ L^T = Lt[:, r]^T @ Lt
+    rec = Lt[:, rows].T @ Lt
+    ref_rows = Kc[rows, :]
+    assert float((rec - ref_rows).abs().max().item()) <= 1e-11
+    sld = float(torch.log(torch.diagonal(Lt)).sum().item())
+    z = torch.linalg.solve_triangular(Lt.T, dy.reshape(-1, 1), upper=False)
+    q = float((z * z).sum().item())
+    lm = -0.5 * q - sld - 0.5 * n * math.log(2 * math.pi)
+    assert abs(sld - o[0, 1]) <= 1e-10 * abs(sld)
+    assert abs(q - o[0, 2]) <= 1e-8 * abs(q)
+    assert abs(lm - o[0, 0]) <= LOGML_RTOL * abs(lm)
+
+
+def test_c3_n8192_vs_lapack(ctx, orc):
+    import scipy.linalg as sla
+    from gp_amd.synth import synth
+    n = 8192
+    X, y = synth(n, 3)
+    got = ctx.logml(X, y, 1.0, [0.3], 0.1)
+    K = orc.cov_exp_quad(X, 1.0, 0.3)
+    K[np.diag_indices(n)] += 0.01
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+    lap = -0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * n * math.log(2 * math.pi)
+    assert abs(got[0] - lap) <= LOGML_RTOL * abs(lap)
+
+
+def test_c4_grid_n8192_subset(ctx):
+    # config c4 (64-point rho x sigma grid at N=8192): a 2 x 2 corner of the grid through the grid
+    # entry point equals single evaluations bit for bit; values order sensibly
+    from gp_amd.synth import synth
+    from gp_amd import stan_models as sm
+    X, y = synth(8192, 3)
+    rho = np.geomspace(0.1, 1.0, 8)[[2, 5]]; sig = np.geomspace(0.05, 0.5, 8)[[1, 6]]
+    G = sm.gp_log_marginal_grid(X, y, 1.0, rho, sig, ctx=ctx)
+    assert G.shape == (2, 2) and np.all(np.isfinite(G))
+    single = ctx.logml(X, y, 1.0, [rho[1]], sig[0])[0]
+    assert G[1, 0] == single
+    best = sm.get_ml_from_grid(G, 1.0, rho, sig)
+    assert best["rho"] in rho and best["sigma"] in sig
+
+
+def test_c5_derivative_joint(ctx, orc):
+    # config c5: joint [y, y'] covariance; order-4096 parity against the oracle, order-16384 properties
+    t = np.linspace(0, 10, 2048); yy = np.concatenate([np.sin(t), np.cos(t)])
+    got = ctx.joint_logml(t, yy, 1.0, 0.5, 0.1, 1e-6)
+    want = orc.joint_logml(t, yy, 1.0, 0.5, 0.1, 1e-6)
+    assert want[3] == 0 and abs(got[0] - want[0]) <= 1e-7 * abs(want[0])
+    import torch
+    n = 8192
+    t = np.linspace(0, 10, n); yy = np.concatenate([np.sin(t), np.cos(t)])
+    dev = torch.device("cuda:0")
+    dt = torch.from_numpy(t).to(dev); dyy = torch.from_numpy(yy).to(dev)
+    out = torch.zeros((2, 3), dtype=torch.float64, device=dev); info = torch.zeros(2, dtype=torch.int32, device=dev)
+    ctx.joint_logml_dev(dt.data_ptr(), n, dyy.data_ptr(), 1.0, 0.5, 0.1, 1e-6, out[0].data_ptr(), info[0:].data_ptr())
+    c = 0.6
+    dyc = dyy * c
+    ctx.joint_logml_dev(dt.data_ptr(), n, dyc.data_ptr(), c, 0.5, c * 0.1, c * c * 1e-6, out[1].data_ptr(), info[1:].data_ptr())
+    ctx.sync()
+    o = out.cpu().numpy()
+    assert np.all(info.cpu().numpy() == 0) and np.all(np.isfinite(o))
+    # same scaling identity on the order-16384 joint matrix (jitter scales with c^2)
+    assert abs(o[1, 0] - (o[0, 0] - 2 * n * math.log(c))) <= 1e-7 * abs(o[0, 0])
