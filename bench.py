@@ -50,6 +50,7 @@ def main():
                     help="c3 (default, the metric): N=16384 D=3 evaluations, weak scaling; c4: the 64-point "
                          "rho x sigma grid at N=8192 sharded over the ranks (strong scaling); c5: derivative "
                          "joint [y, y'] covariance, N=8192 (matrix order 16384)")
+    ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU in c4 (0 = auto)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +96,8 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     cdev = torch.device("cpu") if args.rehearse else dev  # gloo rehearsal: collectives on host tensors
 
+    if args.workload == "c3" and args.grid_lanes > 1:
+        raise SystemExit("--grid-lanes applies to the c4 workload")
     if args.workload == "c3":
         # rank r, step k evaluates its own hyper-parameter point near (rho, sigma) = (0.3, 0.1)
         per_step = 1
@@ -120,26 +123,28 @@ def main():
     dout = torch.zeros((npts, 3), dtype=torch.float64, device=dev)
     dinfo = torch.zeros(npts, dtype=torch.int32, device=dev)
 
-    def run(k):  # one step = per_step evaluations
-        for p in range(k * per_step, (k + 1) * per_step):
-            if args.workload == "c5":
+    if args.grid_lanes:
+        ctx.set_option("grid_lanes", args.grid_lanes)
+
+    def run_points(lo, hi):
+        """Evaluate points lo..hi-1 of this rank.  c3 / c4 go through the grid entry point, which
+        overlaps independent points on internal lanes (own workspaces and streams)."""
+        if args.workload == "c5":
+            for p in range(lo, hi):
                 ctx.joint_logml_dev(dX.data_ptr(), n, dy.data_ptr(), 1.0, rho[p], sig[p], 1e-6,
                                     dout[p].data_ptr(), dinfo[p:].data_ptr())
-            else:
-                ctx.logml_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), 1.0, [rho[p]], sig[p], 0.0,
-                              dout[p].data_ptr(), dinfo[p:].data_ptr())
+        else:
+            ctx.logml_grid_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), np.ones(hi - lo), rho[lo:hi], sig[lo:hi], 0.0,
+                               dout[lo].data_ptr(), dinfo[lo:].data_ptr())
 
-    for k in range(warm):
-        run(k)
+    if warm:
+        run_points(0, warm * per_step)
     torch.cuda.synchronize(dev)
-    ctx.set_option("kernel_timing", 1)
-    ctx.kernel_timing(reset=True)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(warm, warm + steps):
-        run(k)
+    run_points(warm * per_step, (warm + steps) * per_step)  # exactly `steps` steps
     if distributed:
         # the path's only collective: gather the per-point results (3 doubles per point)
         send = dout.to(cdev)
@@ -150,8 +155,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    kt = ctx.kernel_timing(reset=True)
-    ctx.set_option("kernel_timing", 0)
+
+    # Roofline pass (same run, rank 0 only, after the timed region): the same evaluations one at
+    # a time with HIP-event pairs around every covariance-build and trailing-update launch on
+    # the launch stream.  Done separately because concurrent lanes overlap launches, which makes
+    # per-launch durations meaningless inside the throughput region.
+    kt = {"syrk": (0, 0.0, 0.0), "build": (0, 0.0, 0.0)}
+    seq_ms = None
+    if rank == 0:
+        ctx.set_option("grid_lanes", 1)
+        ctx.set_option("lookahead", 0)   # nothing else on the chip while a bracketed launch runs
+        ctx.set_option("kernel_timing", 1)
+        ctx.kernel_timing(reset=True)
+        nprof = min(steps * per_step, 4)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        lo = warm * per_step
+        for p in range(lo, lo + nprof):
+            run_points(p, p + 1)
+        torch.cuda.synchronize(dev)
+        seq_ms = 1e3 * (time.perf_counter() - t1) / nprof
+        kt = ctx.kernel_timing(reset=True)
+        ctx.set_option("kernel_timing", 0)
+        ctx.set_option("lookahead", -1)
+        ctx.set_option("grid_lanes", args.grid_lanes)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if distributed:
@@ -160,6 +187,20 @@ def main():
     res = dout.cpu().numpy()
     info = dinfo.cpu().numpy()
     ok = bool(np.all(info == 0) and np.all(np.isfinite(res[:, 0])))
+
+    def pmc_traffic(kernel_substr):
+        """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes over this same
+        command (tools/pmc_bench.sh; FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as
+        MI355X_MICROARCH.md prescribes for gfx950).  None when no PMC summary is committed."""
+        path = os.path.join(ROOT, "profiles", "r01_pmc_bench_%s.json" % args.workload)
+        try:
+            with open(path) as f:
+                for name, e in json.load(f).items():
+                    if kernel_substr in name and "hbm_bytes_per_launch" in e:
+                        return e["hbm_bytes_per_launch"], e.get("mfma_util"), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            pass
+        return None, None, None
 
     if rank == 0:
         evals = steps * (64 if args.workload == "c4" else world * per_step)
@@ -194,16 +235,23 @@ def main():
                        "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1, "nb_outer": args.nb_outer or "auto(512)",
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
+            "grid_lanes": args.grid_lanes or "auto(4)",
+            "ms_per_eval_sequential": seq_ms,
             "logml_first": float(res[warm * per_step, 0]),
             "cholesky_tflops_per_gpu_whole_eval": chol_flops * evals / world / elapsed / 1e12,
             "roofline": {
                 "kernel": "k_gemm_nt<1> (trailing-update SYRK, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
+                "measured_in": "instrumented sequential pass of the same evaluations in this run "
+                               "(lanes=1, look-ahead off: bracketed launches run alone on the chip)",
                 "achieved": ach,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_gemm_nt<1>")[0],
+                "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)",
+                "traffic_source": pmc_traffic("k_gemm_nt<1>")[2],
+                "mfma_util_pmc": pmc_traffic("k_gemm_nt<1>")[1],
                 "launches": int(syrk_n),
                 "avg_launch_ms": syrk_ms / max(syrk_n, 1),
                 "flops_per_launch_avg": syrk_flops / max(syrk_n, 1),
@@ -216,7 +264,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (build_bytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if build_ms > 0 else 0.0,
-                "traffic": None,
+                "traffic": pmc_traffic("k_joint_cov" if args.workload == "c5" else "k_se_cov<3>")[0],
+                "algorithmic_bytes_per_launch": build_bytes / max(build_n, 1),
                 "avg_launch_ms": build_ms / max(build_n, 1),
             },
         }

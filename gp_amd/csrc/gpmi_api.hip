@@ -135,6 +135,8 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
         HIPCHK(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evU, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
         c->lookahead = -1;  // auto: on for large factorisations (see launch_potrf_partial)
         c->cu_reserve = 8;
         c->cu_mask_mode = 1;
@@ -173,6 +175,10 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
             hipStreamDestroy(c->mstream);
         }
         hipEventDestroy(c->evM);
+        hipEventDestroy(c->evFork);
+        hipEventDestroy(c->evJoin);
+        for (int l = 0; l < 7; ++l)
+            if (c->lane[l]) gpmi_destroy(c->lane[l]);
         hipEventDestroy(c->evP);
         hipEventDestroy(c->evU);
         hipStreamDestroy(c->own_stream);
@@ -229,6 +235,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     if (!strcmp(name, "gemm_variant")) {
         extern int g_gemm_variant;
         g_gemm_variant = value;
+        return 0;
+    }
+    if (!strcmp(name, "grid_lanes")) {
+        if (value < 0 || value > 8) return gpmi_fail(GPMI_EARG, "grid_lanes must be 0 (auto) .. 8");
+        c->grid_lanes = value;
         return 0;
     }
     if (!strcmp(name, "lookahead")) {  // 0 off, 1 on, -1 auto
@@ -593,12 +604,40 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
     if (G == 0) return 0;
     if (n <= 0 || !dX || !dy || !alpha || !rho || !sigma || !d_out3 || !d_info || ldx < n)
         return gpmi_fail(GPMI_EARG, "bad argument");
+    // Independent points fan out over `lanes` internal contexts (own workspaces and streams):
+    // while one point is in its latency-bound panel phase or in the tail of a trailing update,
+    // another point's bulk update fills the chip.  Lanes fork from / join into the caller's stream.
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
+    if (lanes > 8) lanes = 8;
+    if (lanes > G) lanes = G;
+    for (int l = 1; l < lanes; ++l) {
+        if (!c->lane[l - 1]) {
+            int rc = gpmi_create(&c->lane[l - 1], c->device);
+            if (rc) return rc;
+        }
+        c->lane[l - 1]->nb_outer = c->nb_outer;
+        c->lane[l - 1]->lookahead = 0;  // concurrent lanes already fill the panel phases
+    }
+    const int la_saved = c->lookahead;
+    if (lanes > 1) c->lookahead = 0;
+    if (lanes > 1) {
+        HIPCHK(hipEventRecord(c->evFork, c->stream));
+        for (int l = 1; l < lanes; ++l) HIPCHK(hipStreamWaitEvent(c->lane[l - 1]->stream, c->evFork, 0));
+    }
     for (int g = 0; g < G; ++g) {
         SeParams p;
         int rc = fill_params(&p, D, alpha[g], &rho[g], 1);
-        if (rc) return rc;
-        if ((rc = logml_core(c, dX, n, ldx, dy, p, sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g)))
+        gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
+        if (!rc) rc = logml_core(lc, dX, n, ldx, dy, p, sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g);
+        if (rc) {
+            c->lookahead = la_saved;
             return rc;
+        }
+    }
+    c->lookahead = la_saved;
+    for (int l = 1; l < lanes; ++l) {
+        HIPCHK(hipEventRecord(c->lane[l - 1]->evJoin, c->lane[l - 1]->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->lane[l - 1]->evJoin, 0));
     }
     return 0;
 }

@@ -48,6 +48,11 @@ struct gpmi_ctx {
     // 2 panel kernels (diag potrf + panel solve + in-block update)
     int ktiming;
     void *ktimer;            // KTimer*
+    // grid lanes: extra internal contexts (own workspace + streams) so that independent grid
+    // points overlap -- one point's panel phase and SYRK tails run under another's bulk update
+    int grid_lanes;          // 0 = auto
+    gpmi_ctx *lane[7];
+    hipEvent_t evFork, evJoin;
 };
 
 // event-pair recorder; begin/end bracket one launch on the context's stream
