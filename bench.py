@@ -51,6 +51,8 @@ def main():
                          "rho x sigma grid at N=8192 sharded over the ranks (strong scaling); c5: derivative "
                          "joint [y, y'] covariance, N=8192 (matrix order 16384)")
     ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU in c4 (0 = auto)")
+    ap.add_argument("--lookahead", type=int, default=-1, choices=[-1, 0, 1],
+                    help="panel look-ahead inside one factorisation: -1 auto, 0 off, 1 on")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,6 +127,7 @@ def main():
 
     if args.grid_lanes:
         ctx.set_option("grid_lanes", args.grid_lanes)
+    ctx.set_option("lookahead", args.lookahead)
 
     def run_points(lo, hi):
         """Evaluate points lo..hi-1 of this rank.  c3 / c4 go through the grid entry point, which
@@ -177,7 +180,7 @@ def main():
         seq_ms = 1e3 * (time.perf_counter() - t1) / nprof
         kt = ctx.kernel_timing(reset=True)
         ctx.set_option("kernel_timing", 0)
-        ctx.set_option("lookahead", -1)
+        ctx.set_option("lookahead", args.lookahead)
         ctx.set_option("grid_lanes", args.grid_lanes)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)

@@ -8,6 +8,8 @@ G = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ctx = gp_amd.Context(0)
 if len(sys.argv) > 4:
     ctx.set_option("lookahead", int(sys.argv[4]))
+if len(sys.argv) > 5:
+    ctx.set_option("nb_outer", int(sys.argv[5]))
 X, y = synth(n, 3)
 dev = torch.device("cuda:0")
 dX = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev); dy = torch.from_numpy(y).to(dev)
