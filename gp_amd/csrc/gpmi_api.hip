@@ -318,11 +318,11 @@ static int scratch_buf(gpmi_ctx *c, size_t bytes, double **out)
 
 static int fill_params(SeParams *p, int D, double alpha, const double *ell, int n_ell)
 {
-    if (D < 1 || D > GPMI_MAXD) return gpmi_fail(GPMI_EARG, "D = %d unsupported (1..%d)", D, GPMI_MAXD);
+    if (D < 1 || D > GPMI_MAXD_BIG) return gpmi_fail(GPMI_EARG, "D = %d unsupported (1..%d)", D, GPMI_MAXD_BIG);
     if (!ell || (n_ell != 1 && n_ell != D)) return gpmi_fail(GPMI_EARG, "length-scale vector must have length 1 or D");
     p->a2 = alpha * alpha;
     p->D = D;
-    for (int d = 0; d < GPMI_MAXD; ++d) p->inv_ell[d] = 0.0;
+    for (int d = 0; d < GPMI_MAXD_BIG; ++d) p->inv_ell[d] = 0.0;
     for (int d = 0; d < D; ++d) {
         const double l = ell[n_ell == 1 ? 0 : d];
         if (!(l > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");

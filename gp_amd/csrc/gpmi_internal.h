@@ -6,13 +6,14 @@
 
 #define GPMI_NB 128          // inner panel width == diagonal-block order
 #define GPMI_FPACK 9216      // doubles in one packed panel-factor buffer (36 tiles x 256)
-#define GPMI_MAXD 8          // dimensions carried inline in kernel arguments
+#define GPMI_MAXD 8          // dimensions the register-resident fast path handles
+#define GPMI_MAXD_BIG 64     // dimensions the generic path handles (inverse length-scales in kernel arguments)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct SeParams {            // squared-exponential hyper-parameters, kernel-argument resident
     double a2;               // alpha^2
-    double inv_ell[GPMI_MAXD];
+    double inv_ell[GPMI_MAXD_BIG];
     int D;
 };
 

@@ -74,6 +74,41 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
     }
 }
 
+// Same for D > GPMI_MAXD (R's QQard takes any D): coordinates are re-read per element (L1/L2
+// resident), nothing is held in per-dimension registers.
+__global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X, int n, int ldx,
+                                                    const double *__restrict__ Y, int m, int ldy,
+                                                    SeParams p, double diag_add, int same, int lower,
+                                                    double *__restrict__ K, size_t ldk, int vec)
+{
+    const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
+    if (lower && col0 > row0 + TILE - 1) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r = row0 + 2 * tx;
+    const bool ok0 = r < n, ok1 = r + 1 < n;
+    const int ra = ok0 ? r : 0, rb = ok1 ? r + 1 : 0;
+    for (int q = 0; q < 8; ++q) {
+        const int c = col0 + ty * 8 + q;
+        if (c >= m) break;
+        double s0 = 0.0, s1 = 0.0;
+        for (int d = 0; d < p.D; ++d) {
+            const double ie = p.inv_ell[d];
+            const double yv = __dmul_rn(Y[(size_t)c + (size_t)d * ldy], ie);
+            const double d0 = __dsub_rn(__dmul_rn(X[(size_t)ra + (size_t)d * ldx], ie), yv);
+            const double d1 = __dsub_rn(__dmul_rn(X[(size_t)rb + (size_t)d * ldx], ie), yv);
+            s0 = fma(d0, d0, s0);
+            s1 = fma(d1, d1, s1);
+        }
+        double v0 = p.a2 * exp(-0.5 * s0), v1 = p.a2 * exp(-0.5 * s1);
+        if (same) {
+            if (r == c) v0 = p.a2 + diag_add;
+            if (r + 1 == c) v1 = p.a2 + diag_add;
+        }
+        const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
+        store_pair(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
+    }
+}
+
 // derivative_kernels.R:39-73 with unit amplitude; r = tj - tk, e = exp(-r^2/(2 l^2)).
 __device__ __forceinline__ double deriv_val(int kind, double tj, double tk, double l2)
 {
@@ -254,7 +289,12 @@ void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double
     case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
     case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
     case 3: hipLaunchKernelGGL(k_se_cov<3>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
-    default: hipLaunchKernelGGL(k_se_cov<0>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
+    default:
+        if (p.D <= GPMI_MAXD)
+            hipLaunchKernelGGL(k_se_cov<0>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec);
+        else
+            hipLaunchKernelGGL(k_se_cov_big, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec);
+        break;
     }
 }
 

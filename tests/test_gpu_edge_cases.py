@@ -1,0 +1,131 @@
+"""GPU: edge cases and error behaviour of the C ABI (empty / ragged inputs, bad arguments,
+non-PD handling, fork detection, option handling)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_arguments_are_status_codes(ctx):
+    import gp_amd
+    X = np.random.default_rng(0).random((10, 2)); y = np.zeros(10)
+    with pytest.raises(gp_amd.GpmiError) as e:
+        ctx.logml(X, np.zeros(9), 1.0, [0.3], 0.1)  # X and y disagree on N
+    assert e.value.code == -1
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.logml(X, y, 1.0, [0.3, 0.2, 0.1], 0.1)  # length-scale vector neither 1 nor D
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.logml(X, y, 1.0, [0.0], 0.1)  # non-positive length-scale
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.deriv_cov(11, [0.0], [0.0], 1.0, 1.0)  # unknown kernel kind
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.set_option("nb_outer", 100)  # not a multiple of 128
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.joint_logml([0.0, 1.0], [0.0, 1.0, 2.0], 1.0, 1.0, 0.1)  # yy must have length 2N
+    # the context is still healthy
+    assert math.isfinite(ctx.logml(X, y + 1.0, 1.0, [0.3], 0.1)[0])
+
+
+def test_empty_inputs(ctx):
+    assert ctx.deriv_cov("QQ", [], [], 1.0, 1.0).shape == (0, 0)
+    assert ctx.deriv_cov("RR", [0.0, 1.0], [], 1.0, 1.0).shape == (2, 0)
+    assert ctx.deriv_elem("TT", [], [], 1.0).shape == (0,)
+    assert ctx.joint_cov([], 1.0, 1.0, 0.1).shape == (0, 0)
+    assert ctx.potrf(np.zeros((0, 0))).shape == (0, 0)
+    out, info = ctx.logml_grid(np.zeros((5, 1)) + np.arange(5)[:, None], np.ones(5), [], [], [])
+    assert out.shape == (0, 3) and info.shape == (0,)
+
+
+def test_ard_length_scales_and_1d_inputs(ctx, orc):
+    # ARD (length-D phi2) through the marginal likelihood; 1-D x given as a plain vector
+    rng = np.random.default_rng(3)
+    X = rng.random((90, 3)); y = rng.standard_normal(90)
+    ell = [0.2, 0.5, 1.5]
+    got = ctx.logml(X, y, 1.1, ell, 0.2)
+    K = orc.QQard(X, X, 1.1, ell) + 0.04 * np.eye(90)
+    L = np.linalg.cholesky(K); z = np.linalg.solve(L, y)
+    want = -0.5 * z @ z - np.log(np.diag(L)).sum() - 45 * math.log(2 * math.pi)
+    assert abs(got[0] - want) <= 1e-9 * abs(want)
+    x = np.linspace(0, 4, 33)
+    a = ctx.logml(x, np.sin(x), 1.0, [0.7], 0.1)
+    b = ctx.logml(x.reshape(-1, 1), np.sin(x), 1.0, [0.7], 0.1)
+    assert a == b
+
+
+def test_every_pivot_position_reports_its_order(ctx):
+    # the first non-positive pivot is reported 1-based, LAPACK style, wherever it sits in the
+    # 16 x 16 / 128 x 128 / outer-block hierarchy
+    import gp_amd
+    for k in (1, 16, 17, 128, 129, 255, 256, 257, 400):
+        n = k + 37
+        A = np.eye(n) * 2.0
+        A[k - 1, k - 1] = -1.0
+        with pytest.raises(gp_amd.NotPositiveDefinite) as e:
+            ctx.potrf(A)
+        assert e.value.order == k, (k, e.value.order)
+    # semi-definite (exactly singular) also fails like dpotrf
+    B = np.ones((40, 40))
+    with pytest.raises(gp_amd.NotPositiveDefinite) as e:
+        ctx.potrf(B)
+    assert e.value.order == 2
+
+
+def test_nan_input_is_flagged_not_crashed(ctx):
+    X = np.linspace(0, 1, 50).reshape(-1, 1); y = np.ones(50); y[7] = np.nan
+    r = ctx.logml(X, y, 1.0, [0.3], 0.1)
+    assert math.isnan(r[0]) or math.isnan(r[2])
+
+
+def test_context_is_rejected_in_forked_child(ctx):
+    # HIP state does not survive fork(): the parent's context must answer GPMI_EFORK (-5) in a
+    # child (the reference drivers fork with parallel::mclapply, pendulum_fit.R:268)
+    from gp_amd import _lib
+    h = _lib.load()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            rc = h.gpmi_sync(ctx._h)
+            os.write(w, str(rc).encode())
+        finally:
+            os._exit(0)
+    os.close(w)
+    os.waitpid(pid, 0)
+    rc = int(os.read(r, 16).decode() or "0")
+    os.close(r)
+    assert rc == -5
+    assert math.isfinite(ctx.logml(np.arange(5.0), np.ones(5), 1.0, [1.0], 0.5)[0])  # parent unaffected
+
+
+def test_options_do_not_change_results_beyond_rounding(ctx, orc):
+    X, y = orc.synth(900, 3)
+    base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+    vals = []
+    for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("lookahead", 1), ("lookahead", 0), ("gemm_variant", 0),
+                   ("gemm_variant", 1), ("gemm_variant", 2), ("syrk_order", 1)):
+        ctx.set_option(opt, v)
+        try:
+            vals.append(ctx.logml(X, y, 1.0, [0.3], 0.1)[0])
+        finally:
+            ctx.set_option("nb_outer", 0); ctx.set_option("lookahead", -1)
+            ctx.set_option("gemm_variant", 3); ctx.set_option("syrk_order", 0)
+    assert all(abs(v - base) <= 1e-10 * abs(base) for v in vals), (base, vals)
+
+
+def test_grid_lanes_match_single_evaluations(ctx, orc):
+    X, y = orc.synth(700, 2)
+    rho = np.geomspace(0.1, 1.0, 7); sig = np.geomspace(0.05, 0.5, 7)
+    for lanes in (1, 2, 4, 8):
+        ctx.set_option("grid_lanes", lanes)
+        try:
+            out, info = ctx.logml_grid(X, y, 1.0, rho, sig)
+        finally:
+            ctx.set_option("grid_lanes", 0)
+        assert np.all(info == 0)
+        for g in (0, 3, 6):
+            assert out[g, 0] == ctx.logml(X, y, 1.0, [rho[g]], sig[g])[0]  # bit-identical
