@@ -939,6 +939,7 @@ __global__ __launch_bounds__(256) void k_probe_peak(double *sink, int iters)
 // ---------------------------------------------------------------------------
 int g_syrk_order = 0;    // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
 int g_gemm_variant = 3;
+int g_rect_auto = 0;      // 1: small rectangular launches use the ring kernel (measured: no gain)
 int g_stagger = (2 << 16) | 4;       // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup  // 0: v1 (4 waves, RMW epilogue), 1: v2 (8 waves, prefetched C)
 
 void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
@@ -946,7 +947,12 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
-    if (g_gemm_variant == 2) {
+    // Launches with fewer tiles than workgroup slots are latency-bound (one tile per CU, every
+    // k-step exposes the DMA latency): the 3-buffer-ring kernel (DMA two steps ahead, C tile
+    // prefetched) has the shorter per-tile time there; the 2-workgroup-per-CU kernel wins once
+    // several rounds of tiles keep each CU's pair of workgroups busy.
+    const bool few_tiles = g_rect_auto && (int)(grid.x * grid.y) <= 384;
+    if (g_gemm_variant == 2 || (g_gemm_variant == 3 && few_tiles)) {
         if (accumulate_minus)
             hipLaunchKernelGGL(k_gemm9<0>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
         else
@@ -1001,7 +1007,7 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     // kernels: Panel(s+1) touches block s+1's columns, U2(s) reads block s and writes >= s+2.
     // outer block width: K of the trailing update.  512 halves the C traffic and the number of
     // epilogues once the trailing matrix is large; 256 keeps the panel phase short otherwise.
-    const int NBO = c->nb_outer > 0 ? c->nb_outer : (nfac >= 12288 ? 512 : 256);
+    const int NBO = c->nb_outer > 0 ? c->nb_outer : (nfac >= 12288 ? 1024 : (nfac >= 6144 ? 512 : 256));
     // look-ahead pays once the trailing update dominates (measured: N >= ~12k on MI355X)
     const bool want_la = c->lookahead > 0 || (c->lookahead < 0 && nfac >= 12288);
     const bool la = want_la && c->pstream && nfac > NBO;
@@ -1024,18 +1030,29 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
         const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
         // ---- Panel(s)
         if (!la) kt_begin(c, 2, sm);
-        for (int k = ko; k < ke; k += NB) {
-            const int kb = (ke - k < NB) ? ke - k : NB;
-            double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK : c->Fpack;
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, sp, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
-                               d_info, k);
-            const int r0 = k + kb;
-            if (r0 < M)
-                hipLaunchKernelGGL(k_trsm_panel, dim3((M - r0 + 63) / 64), 256, 0, sp, W + (size_t)k * ld, ld,
-                                   r0, M, kb, Fp);
-            if (r0 < ke)  // rest of this outer block's columns: rows [r0, M) x cols [r0, ke), K = kb
-                launch_gemm_nt(sp, W + (size_t)r0 + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
-                               W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, ke - r0, kb, 1);
+        // Three blocking levels inside the outer block: 128-column panels, grouped into middle
+        // blocks of NBM columns.  A panel's K = 128 update reaches only to the end of its middle
+        // block; the rest of the outer block is updated once per middle block with K = NBM
+        // (the K = 128 GEMM runs at ~60 % of the K = 256 one's rate).
+        const int NBM = (NBO >= 512) ? 256 : NBO;
+        for (int km = ko; km < ke; km += NBM) {
+            const int kme = (km + NBM < ke) ? km + NBM : ke;
+            for (int k = km; k < kme; k += NB) {
+                const int kb = (kme - k < NB) ? kme - k : NB;
+                double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK : c->Fpack;
+                hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, sp, W + (size_t)k + (size_t)k * ld, ld, kb,
+                                   Fp, d_info, k);
+                const int r0 = k + kb;
+                if (r0 < M)
+                    hipLaunchKernelGGL(k_trsm_panel, dim3((M - r0 + 63) / 64), 256, 0, sp, W + (size_t)k * ld,
+                                       ld, r0, M, kb, Fp);
+                if (r0 < kme)  // rest of this middle block: rows [r0, M) x cols [r0, kme), K = kb
+                    launch_gemm_nt(sp, W + (size_t)r0 + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
+                                   W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, kme - r0, kb, 1);
+            }
+            if (kme < ke)  // rest of the outer block: rows [kme, M) x cols [kme, ke), K = kme - km
+                launch_gemm_nt(sp, W + (size_t)kme + (size_t)km * ld, ld, W + (size_t)kme + (size_t)km * ld, ld,
+                               W + (size_t)kme + (size_t)kme * ld, ld, M - kme, ke - kme, kme - km, 1);
         }
         if (la) {
             hipEventRecord(c->evP, sp);

@@ -222,6 +222,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         else c->cu_mask_mode = value;
         return ensure_mstream(c);
     }
+    if (!strcmp(name, "rect_auto")) {
+        extern int g_rect_auto;
+        g_rect_auto = value;
+        return 0;
+    }
     if (!strcmp(name, "stagger")) {
         extern int g_stagger;
         g_stagger = value;
@@ -235,6 +240,10 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     if (!strcmp(name, "gemm_variant")) {
         extern int g_gemm_variant;
         g_gemm_variant = value;
+        return 0;
+    }
+    if (!strcmp(name, "lane_lookahead")) {
+        c->lane_lookahead = value != 0;
         return 0;
     }
     if (!strcmp(name, "grid_lanes")) {
@@ -282,7 +291,16 @@ extern "C" int gpmi_reserve(gpmi_ctx *c, int n_max)
 {
     ENTER(c);
     if (n_max <= 0) return gpmi_fail(GPMI_EARG, "n_max must be positive");
-    return reserve_ws(c, n_max + 1, n_max + 1);
+    int rc = reserve_ws(c, n_max + 1, n_max + 1);
+    if (rc) return rc;
+    // also the grid lanes (contexts, streams, workspaces), so that no allocation happens later
+    // inside a grid call: up to 5 lanes are used in auto mode
+    const int lanes = c->grid_lanes > 0 ? c->grid_lanes : 5;
+    for (int l = 1; l < lanes && l <= 7; ++l) {
+        if (!c->lane[l - 1] && (rc = gpmi_create(&c->lane[l - 1], c->device))) return rc;
+        if ((rc = reserve_ws(c->lane[l - 1], n_max + 1, n_max + 1))) return rc;
+    }
+    return 0;
 }
 
 static int stage_buf(gpmi_ctx *c, int slot, size_t bytes, double **out)
@@ -607,7 +625,8 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
     // Independent points fan out over `lanes` internal contexts (own workspaces and streams):
     // while one point is in its latency-bound panel phase or in the tail of a trailing update,
     // another point's bulk update fills the chip.  Lanes fork from / join into the caller's stream.
-    int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
+    // auto: 4 lanes, or 3 / 5 when that splits the grid evenly (all points cost the same)
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : (G % 5 == 0 ? 5 : 4)));
     if (lanes > 8) lanes = 8;
     if (lanes > G) lanes = G;
     for (int l = 1; l < lanes; ++l) {
@@ -615,11 +634,22 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
             int rc = gpmi_create(&c->lane[l - 1], c->device);
             if (rc) return rc;
         }
-        c->lane[l - 1]->nb_outer = c->nb_outer;
-        c->lane[l - 1]->lookahead = 0;  // concurrent lanes already fill the panel phases
+        gpmi_ctx *lc = c->lane[l - 1];
+        lc->nb_outer = c->nb_outer;
+        lc->lookahead = c->lane_lookahead;  // default 0: concurrent lanes already fill the panel phases
+        if (lc->cu_reserve != c->cu_reserve) {  // same CU reservation as the parent
+            if (lc->mstream) {
+                HIPCHK(hipStreamSynchronize(lc->mstream));
+                HIPCHK(hipStreamDestroy(lc->mstream));
+                lc->mstream = nullptr;
+            }
+            lc->cu_reserve = c->cu_reserve;
+            int rc = ensure_mstream(lc);
+            if (rc) return rc;
+        }
     }
     const int la_saved = c->lookahead;
-    if (lanes > 1) c->lookahead = 0;
+    if (lanes > 1) c->lookahead = c->lane_lookahead;
     if (lanes > 1) {
         HIPCHK(hipEventRecord(c->evFork, c->stream));
         for (int l = 1; l < lanes; ++l) HIPCHK(hipStreamWaitEvent(c->lane[l - 1]->stream, c->evFork, 0));

@@ -52,6 +52,7 @@ struct gpmi_ctx {
     // grid lanes: extra internal contexts (own workspace + streams) so that independent grid
     // points overlap -- one point's panel phase and SYRK tails run under another's bulk update
     int grid_lanes;          // 0 = auto
+    int lane_lookahead;      // panel look-ahead inside each lane of a multi-lane grid (default off)
     gpmi_ctx *lane[7];
     hipEvent_t evFork, evJoin;
 };

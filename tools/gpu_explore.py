@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gp_amd  # noqa: E402
 from gp_amd.synth import synth  # noqa: E402
 
-opts = {"n": "16384", "nbo": "256", "la": "1", "gv": "0", "res": "0", "mm": "0", "order": "0", "probe": "0", "stg": "131076"}
+opts = {"n": "16384", "nbo": "256", "la": "1", "gv": "0", "res": "0", "mm": "0", "order": "0", "probe": "0", "stg": "131076", "ra": "1"}
 for a in sys.argv[1:]:
     k, v = a.split("=")
     opts[k] = v
@@ -24,6 +24,7 @@ ctx.set_option("timing", 1)
 for n in L("n"):
     X, y = synth(n, 3)
     for nbo, la, gv, res, mm, order in itertools.product(L("nbo"), L("la"), L("gv"), L("res"), L("mm"), L("order")):
+        ctx.set_option("rect_auto", int(opts["ra"]))
         ctx.set_option("stagger", int(opts["stg"]))
         ctx.set_option("gemm_variant", gv)
         ctx.set_option("syrk_order", order)
