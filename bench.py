@@ -52,7 +52,7 @@ def main():
                          "joint [y, y'] covariance, N=8192 (matrix order 16384)")
     ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU in c4 (0 = auto)")
     ap.add_argument("--lookahead", type=int, default=-1, choices=[-1, 0, 1],
-                    help="panel look-ahead inside one factorisation: -1 auto, 0 off, 1 on")
+                    help="panel look-ahead inside one factorisation: 1 on; 0 / -1 (default) off")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")

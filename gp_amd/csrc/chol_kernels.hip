@@ -164,6 +164,126 @@ __global__ __launch_bounds__(320) void k_potrf_diag(double *__restrict__ A, size
 }
 
 // ---------------------------------------------------------------------------
+// Diagonal block, 4-wave variant: the same algorithm with THREE tile waves (block-rows
+// {7,2,0}, {6,3,1}, {5,4}: 12 / 13 / 11 register tiles) and the factor wave.  One wave per
+// SIMD and ~50 KB of LDS: the workgroup fits into the half of a CU that a retiring
+// trailing-update workgroup leaves behind, so next to a running SYRK it starts within
+// microseconds instead of waiting for a whole CU to drain by chance (5 waves need two wave
+// slots with ~200 registers each on one SIMD, which a resident SYRK wave rules out).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, size_t lda, int nb_act,
+                                                     double *__restrict__ Fpack, int *info, int col0)
+{
+    __shared__ double s_pub[2][8][256];
+    __shared__ double s_inv[8][256];
+    __shared__ double s_d16[16][17];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+
+    if (w == 3) {
+#pragma unroll 1
+        for (int kb = 0; kb < 8; ++kb) {
+            __syncthreads();  // B1: the owner's diagonal tile is in s_d16
+            const int bad = factor16(s_d16, s_inv[kb], lane);
+            if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
+            __syncthreads();  // B2: L16 in s_d16, L16^-1 in s_inv
+            __syncthreads();  // B3: -X tiles published
+        }
+        return;
+    }
+
+    // block-rows of this wave, ra > rb > rc (rc = -1: none); array sizes cover the largest row of each class
+    const int ra = 7 - w, rb = 2 + w, rc = w < 2 ? w : -1;
+    d4 TA[8], TB[5], TC[2];
+#define GPMI_CL(jb, NJ) ((jb) < (NJ) ? (jb) : 0)  // keeps compile-time indices of never-taken branches in range
+#define GPMI_LOAD_ROW(T, NJ, br)                                                                       \
+    _Pragma("unroll") for (int jb = 0; jb < (NJ); ++jb) {                                              \
+        T[jb] = d4{0.0, 0.0, 0.0, 0.0};                                                                \
+        if (jb <= (br)) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
+                const int rr = row > col ? row : col, cc = row > col ? col : row;                      \
+                T[jb][i] = (rr < nb_act) ? A[(size_t)rr + (size_t)cc * lda] : (row == col ? 1.0 : 0.0); \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    GPMI_LOAD_ROW(TA, 8, ra)
+    GPMI_LOAD_ROW(TB, 5, rb)
+    GPMI_LOAD_ROW(TC, 2, rc)
+
+#define GPMI_SOLVE_ROW(T, NJ, br, X)                                                                   \
+    if ((br) == kb) {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) T[GPMI_CL(kb, NJ)][i] = s_d16[lr][lq + 4 * i];   \
+    } else if ((br) > kb) {                                                                            \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
+            X = mfma(s_inv[kb][kg * 64 + lane], T[GPMI_CL(kb, NJ)][kg], X);                            \
+        T[GPMI_CL(kb, NJ)] = X;                                                                        \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) s_pub[kb & 1][br][kg * 64 + lane] = -X[kg];   \
+    }
+#define GPMI_UPDATE_ROW(T, NJ, br, X)                                                                  \
+    _Pragma("unroll") for (int jb = kb + 1; jb < (NJ); ++jb) {                                         \
+        if (jb <= (br)) {                                                                              \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                           \
+                T[jb] = mfma(s_pub[kb & 1][jb][kg * 64 + lane], X[kg], T[jb]);                         \
+        }                                                                                              \
+    }
+
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        // (a) the owner hands its updated diagonal tile to the factor wave in matrix order
+        if (ra == kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TA[kb][i];
+        } else if (rb == kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TB[GPMI_CL(kb, 5)][i];
+        } else if (rc == kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TC[GPMI_CL(kb, 2)][i];
+        }
+        __syncthreads();  // B1
+        __syncthreads();  // B2: factor wave done
+        d4 XA = d4{0.0, 0.0, 0.0, 0.0}, XB = XA, XC = XA;
+        GPMI_SOLVE_ROW(TA, 8, ra, XA)
+        GPMI_SOLVE_ROW(TB, 5, rb, XB)
+        GPMI_SOLVE_ROW(TC, 2, rc, XC)
+        __syncthreads();  // B3
+        if (ra > kb) { GPMI_UPDATE_ROW(TA, 8, ra, XA) }
+        if (rb > kb) { GPMI_UPDATE_ROW(TB, 5, rb, XB) }
+        if (rc > kb) { GPMI_UPDATE_ROW(TC, 2, rc, XC) }
+    }
+
+#define GPMI_STORE_ROW(T, NJ, br)                                                                      \
+    _Pragma("unroll") for (int jb = 0; jb < (NJ); ++jb) {                                              \
+        if (jb <= (br)) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
+                if (row < nb_act && col <= row) A[(size_t)row + (size_t)col * lda] = T[jb][i];         \
+            }                                                                                          \
+            if (jb < (br)) {                                                                           \
+                _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                       \
+                    Fpack[(size_t)((br) * ((br) - 1) / 2 + jb) * 256 + kg * 64 + lane] = -T[jb][kg];   \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    GPMI_STORE_ROW(TA, 8, ra)
+    GPMI_STORE_ROW(TB, 5, rb)
+    GPMI_STORE_ROW(TC, 2, rc)
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+        Fpack[(size_t)fp_inv(ra) * 256 + kg * 64 + lane] = s_inv[ra][kg * 64 + lane];
+        Fpack[(size_t)fp_inv(rb) * 256 + kg * 64 + lane] = s_inv[rb][kg * 64 + lane];
+        if (rc >= 0) Fpack[(size_t)fp_inv(rc) * 256 + kg * 64 + lane] = s_inv[rc][kg * 64 + lane];
+    }
+#undef GPMI_CL
+#undef GPMI_LOAD_ROW
+#undef GPMI_SOLVE_ROW
+#undef GPMI_UPDATE_ROW
+#undef GPMI_STORE_ROW
+}
+
+// ---------------------------------------------------------------------------
 // Panel solve: rows [row0, M) of the nb_act columns starting at Acol.
 // X L11^T = A21 by block forward substitution over the 8 block columns; each
 // wave carries its 16 rows through all steps in registers.
@@ -273,43 +393,17 @@ __host__ inline int syrk_grid(int T, int order)
     return ((ns + 7) / 8) * 8 * ST * ST;
 }
 
+// One 128 x 128 output tile (ti, tj); smem is the workgroup's staging buffer (free on entry:
+// every wave has finished reading it).
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
-                                                 const double *__restrict__ B, size_t ldb,
-                                                 double *__restrict__ C, size_t ldc, int M, int N, int K, int order,
-                                                 int stagger)
+__device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const double *__restrict__ A, size_t lda,
+                                          const double *__restrict__ B, size_t ldb, double *__restrict__ C,
+                                          size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid)
 {
-    __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
-    // Two workgroups share a CU and its matrix pipes.  All tiles cost the same, so workgroups
-    // that start together stay in lock-step: both reach their memory-bound epilogue at the
-    // same time and the pipes idle.  Delaying the second-dispatched workgroup of each CU once,
-    // by about one epilogue, puts the pair in anti-phase for the rest of the launch: one
-    // streams its C tile while the other has the pipes to itself.
-    // stagger = (mode << 16) | sleeps; mode 1: blocks 256..511 (second dispatch round),
-    // mode 2: odd hardware wave slot of wave 0 (HW_REG_HW_ID[3:0]).
-    if (stagger && blockIdx.x < 512) {
-        bool late = false;
-        if ((stagger >> 16) == 1) late = blockIdx.x >= 256;
-        else {
-            if (threadIdx.x == 0) smem[0][0][0][0] = (double)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1);
-            __syncthreads();
-            late = smem[0][0][0][0] != 0.0;
-            __syncthreads();
-        }
-        if (late)
-            for (int i = 0; i < (stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    int ti, tj;
-    if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
-    } else {
-        ti = blockIdx.x;
-        tj = blockIdx.y;
-    }
     const int m0 = ti * GT, n0 = tj * GT;
     if (MODE == 1 && n0 >= N) return;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int wm = w & 1, wn = w >> 1;
 
@@ -386,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     for (int kt = 0; kt < nk - 1; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue((kt + 1) & 1, (kt + 1) * GK);
+        if (!(dbg & 2)) issue((kt + 1) & 1, (kt + 1) * GK);
         compute(ic<0>{}, kt & 1, GK);
     }
 
@@ -410,6 +504,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
                 for (int i = 0; i < 4; ++i) ch[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
     }
     compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK);
+    if (dbg & 1) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sacc += acc[tn][tm][i];
+        if (sacc == 1.2345e300) cbase[0] = sacc;
+        return;
+    }
     if (interior) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
@@ -463,6 +568,112 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     }
 }
 
+
+// Two workgroups share a CU and its matrix pipes.  All tiles cost the same, so workgroups that
+// start together stay in lock-step: both reach their memory-bound epilogue at the same time
+// and the pipes idle.  Delaying the second-dispatched workgroup of each CU once, by about one
+// epilogue, puts the pair in anti-phase for the rest of the launch: one streams its C tile
+// while the other has the pipes to itself.
+// stagger = (mode << 16) | sleeps; mode 1: blocks 256..511 (second dispatch round),
+// mode 2: odd hardware wave slot of wave 0 (HW_REG_HW_ID[3:0]).
+__device__ __forceinline__ void stagger_start(double (&smem)[2][2][GK][GP], int stagger)
+{
+    if ((stagger & 0xffffff) && blockIdx.x < 512) {
+        bool late = false;
+        if (((stagger >> 16) & 0xff) == 1) late = blockIdx.x >= 256;
+        else {
+            if (threadIdx.x == 0) smem[0][0][0][0] = (double)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1);
+            __syncthreads();
+            late = smem[0][0][0][0] != 0.0;
+            __syncthreads();
+        }
+        if (late)
+            for (int i = 0; i < (stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
+                                                 const double *__restrict__ B, size_t ldb,
+                                                 double *__restrict__ C, size_t ldc, int M, int N, int K, int order,
+                                                 int stagger)
+{
+    __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
+    // bits 24+ of `stagger` are probe-only switches (tools/syrk_bench.py): 1 = skip the C
+    // epilogue, 2 = skip the operand streaming of the main loop; used for the cost breakdown
+    // in DESIGN.md, never set by the library itself
+    const int dbg = stagger >> 24;
+    stagger_start(smem, stagger);
+    int ti, tj;
+    if (MODE == 1) {
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
+    } else {
+        ti = blockIdx.x;
+        tj = blockIdx.y;
+    }
+    gemm_tile<MODE>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, (int)threadIdx.x);
+}
+
+// Persistent SYRK: at most two workgroups per CU are launched and each pulls tiles from a
+// counter until none is left.
+//  * Software CU reservation: a workgroup that finds itself on CU 0 of shader engine 0 of its
+//    XCD (8 CUs on MI355X) retires at once, as long as the launch's exit budget lasts; with no
+//    further workgroups to dispatch those CUs stay empty for the whole update.  The panel
+//    kernels of a concurrent stream -- above all the diagonal-block kernel, which needs a whole
+//    CU's LDS and would otherwise wait for a CU to drain by chance while trailing-update
+//    workgroups refill every slot that frees up -- start there without delay.  (The CU-mask
+//    stream API does the same but its queues dispatch markedly slower.)
+//  * A second update queued behind this one gets the CUs as this one's workgroups run out of
+//    tiles: tails overlap, full-speed phases do not interleave.
+// ctr[0] tile counter, ctr[1] retired workgroups, ctr[2] early exits; the last workgroup out
+// zeroes them for the next launch (launches sharing ctr are stream-ordered).
+__global__ __launch_bounds__(256, 2) void k_syrk_persist(const double *__restrict__ P, size_t ldp,
+                                                      double *__restrict__ C, size_t ldc, int M, int N, int K,
+                                                      int order, int stagger, int ntiles, int exit_budget,
+                                                      int *__restrict__ ctr)
+{
+    __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
+    __shared__ int s_next;
+    const int dbg = stagger >> 24;
+    bool leave = false;
+    if (exit_budget > 0) {
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID, all 32 bits
+            const bool reserved_cu = ((hw >> 8) & 0xf) == 0 && ((hw >> 12) & 0x1) == 0 && ((hw >> 13) & 0x7) == 0;
+            s_next = (reserved_cu && atomicAdd(&ctr[2], 1) < exit_budget) ? 1 : 0;
+        }
+        __syncthreads();
+        leave = s_next != 0;
+        __syncthreads();
+    }
+    if (!leave) {
+        stagger_start(smem, stagger);
+        const int T = (M + GT - 1) / GT;
+        for (;;) {
+            if (threadIdx.x == 0) s_next = atomicAdd(&ctr[0], 1);
+            __syncthreads();
+            const int b = __builtin_amdgcn_readfirstlane(s_next);  // wave-uniform: tile indices stay in SGPRs
+            __syncthreads();
+            if (b >= ntiles) break;
+            int ti, tj;
+            if (!syrk_tile(b, T, order, ti, tj)) continue;
+            // opaque copy of the thread index: keeps the lane-derived addresses of one tile from being
+            // hoisted out of the loop, where they would sit on top of the 250-register tile body
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            gemm_tile<1>(smem, P, ldp, P, ldp, C, ldc, M, N, K, ti, tj, dbg, tid);
+        }
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&ctr[1], 1) == (int)gridDim.x - 1) {
+            ctr[0] = 0;
+            ctr[2] = 0;
+            __threadfence();
+            ctr[1] = 0;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // GEMM NT v2: same 128x128 tile and LDS image, 8 waves (2 m x 4 n, 64 x 32 outputs per
@@ -972,8 +1183,11 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
         hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0);
 }
 
+int g_diag_waves = 5;    // 5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
+int g_syrk_persist = 0;  // 0: one workgroup per tile; 1: persistent workgroups; 2: persistent + CU reservation
+
 static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
-                              int N, int K)
+                              int N, int K, int *ctr, int ncu)
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int T = (M + GT - 1) / GT;
@@ -986,105 +1200,143 @@ static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
         hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
         return;
     }
-    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order,
-                       ntiles >= 1024 ? g_stagger : 0);  // only when every CU holds two workgroups for many rounds
+    const int stg = ntiles >= 1024 ? g_stagger : 0;  // only when every CU holds two workgroups for many rounds
+    if (g_syrk_persist && ctr) {
+        const int slots = 2 * (ncu > 0 ? ncu : 256);
+        const int grid = ntiles < slots ? ntiles : slots;
+        // reservation only for launches that would otherwise hold every CU for a long time
+        const int budget = (g_syrk_persist == 2 && ntiles >= 2 * slots) ? 16 : 0;
+        hipLaunchKernelGGL(k_syrk_persist, dim3(grid), 256, 0, s, P, ldp, C, ldc, M, N, K, g_syrk_order, stg, ntiles,
+                           budget, ctr);
+        return;
+    }
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg);
 }
 
-void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k)
+void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
+                       int ncu)
 {
-    launch_syrk_lower(s, P, ldp, C, ldc, m, m, k);
+    launch_syrk_lower(s, P, ldp, C, ldc, m, m, k, ctr, ncu);
+}
+
+// Panel work of one outer block [ko, ke) restricted to the rows [row_lo, row_hi) below each
+// panel.  Three blocking levels: 128-column panels, grouped into middle blocks of NBM columns.
+// A panel's K = 128 update reaches only to the end of its middle block; the rest of the outer
+// block is updated once per middle block with K = NBM (the K = 128 GEMM runs at ~60 % of the
+// K = 256 one's rate).  with_diag: also factor the 128 x 128 diagonal blocks (their factors go
+// to the block's Fpack slots); without it the slots written by an earlier call are used.
+//   (0, M, true)   : the whole panel phase, full height
+//   (0, ke, true)  : only the NBO x NBO diagonal block -- the latency chain of the look-ahead
+//   (ke, M, false) : the rows below it -- wide, throughput-bound kernels
+static void panel_rows(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int ke, int NBO,
+                       int row_lo, int row_hi, bool with_diag, hipStream_t s)
+{
+    const int NB = GPMI_NB;
+    const int NBM = (NBO >= 512) ? 256 : NBO;
+    for (int km = ko; km < ke; km += NBM) {
+        const int kme = (km + NBM < ke) ? km + NBM : ke;
+        for (int k = km; k < kme; k += NB) {
+            const int kb = (kme - k < NB) ? kme - k : NB;
+            double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK
+                                   : c->Fpack + (size_t)(((k - ko) / NB) % GPMI_FPACK_SLOTS) * GPMI_FPACK;
+            if (with_diag) {
+                if (g_diag_waves == 4)
+                    hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
+                                       d_info, k);
+                else
+                    hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
+                                       d_info, k);
+            }
+            const int r0 = k + kb;
+            const int rlo = r0 > row_lo ? r0 : row_lo;
+            if (rlo >= row_hi) continue;
+            hipLaunchKernelGGL(k_trsm_panel, dim3((row_hi - rlo + 63) / 64), 256, 0, s, W + (size_t)k * ld, ld, rlo,
+                               row_hi, kb, Fp);
+            if (r0 < kme)  // rest of this middle block: rows [rlo, row_hi) x cols [r0, kme), K = kb
+                launch_gemm_nt(s, W + (size_t)rlo + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
+                               W + (size_t)rlo + (size_t)r0 * ld, ld, row_hi - rlo, kme - r0, kb, 1);
+        }
+        const int rlo = kme > row_lo ? kme : row_lo;
+        if (kme < ke && rlo < row_hi)  // rest of the outer block: cols [kme, ke), K = kme - km
+            launch_gemm_nt(s, W + (size_t)rlo + (size_t)km * ld, ld, W + (size_t)kme + (size_t)km * ld, ld,
+                           W + (size_t)rlo + (size_t)kme * ld, ld, row_hi - rlo, ke - kme, kme - km, 1);
+    }
 }
 
 int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int nfac, int *d_info,
                          double *Fpack_all)
 {
-    // Right-looking with one-block look-ahead.  Per outer block s of NBO columns:
-    //   Panel(s)  : [diag potrf, panel solve, in-block update] x (NBO/128)     -> panel stream
-    //   U1(s)     : update of the NEXT block's NBO columns (rect GEMM, K = NBO)  -> main stream
-    //   U2(s)     : SYRK of everything right of them (the bulk of the flops)    -> main stream
-    // Panel(s+1) needs only U1(s), so it runs on the high-priority panel stream while U2(s)
-    // fills the chip; U1(s+1) waits for Panel(s+1).  No data is shared between concurrent
-    // kernels: Panel(s+1) touches block s+1's columns, U2(s) reads block s and writes >= s+2.
-    // outer block width: K of the trailing update.  512 halves the C traffic and the number of
-    // epilogues once the trailing matrix is large; 256 keeps the panel phase short otherwise.
+    // Blocked right-looking factorisation of the leading nfac columns of the M x ncol lower
+    // trapezoid in W; the trailing [nfac, ncol) part receives the Schur complement.
+    // outer block width: K of the trailing update.  Wider blocks cut the C traffic and the
+    // number of epilogues once the trailing matrix is large; 256 keeps the panel phase short.
     const int NBO = c->nb_outer > 0 ? c->nb_outer : (nfac >= 12288 ? 1024 : (nfac >= 6144 ? 512 : 256));
-    // look-ahead pays once the trailing update dominates (measured: N >= ~12k on MI355X)
-    const bool want_la = c->lookahead > 0 || (c->lookahead < 0 && nfac >= 12288);
-    const bool la = want_la && c->pstream && nfac > NBO;
-    // with look-ahead the trailing updates may run on a CU-masked stream that leaves a few CUs
-    // free, so that the panel kernels (which fit nowhere next to two resident SYRK
-    // workgroups) are not starved by the thousands of queued trailing-update workgroups
-    const bool masked = la && c->cu_reserve > 0 && c->mstream;
-    hipStream_t sm = masked ? c->mstream : c->stream;
-    hipStream_t sp = la ? c->pstream : sm;
-    const int NB = GPMI_NB;
-    if (masked) {
-        hipEventRecord(c->evM, c->stream);
-        hipStreamWaitEvent(sm, c->evM, 0);
-    }
-    if (la) {
-        hipEventRecord(c->evU, sm);  // panel stream starts after everything already queued on main
-        hipStreamWaitEvent(sp, c->evU, 0);
-    }
-    for (int ko = 0; ko < nfac; ko += NBO) {
-        const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
-        // ---- Panel(s)
-        if (!la) kt_begin(c, 2, sm);
-        // Three blocking levels inside the outer block: 128-column panels, grouped into middle
-        // blocks of NBM columns.  A panel's K = 128 update reaches only to the end of its middle
-        // block; the rest of the outer block is updated once per middle block with K = NBM
-        // (the K = 128 GEMM runs at ~60 % of the K = 256 one's rate).
-        const int NBM = (NBO >= 512) ? 256 : NBO;
-        for (int km = ko; km < ke; km += NBM) {
-            const int kme = (km + NBM < ke) ? km + NBM : ke;
-            for (int k = km; k < kme; k += NB) {
-                const int kb = (kme - k < NB) ? kme - k : NB;
-                double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK : c->Fpack;
-                hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, sp, W + (size_t)k + (size_t)k * ld, ld, kb,
-                                   Fp, d_info, k);
-                const int r0 = k + kb;
-                if (r0 < M)
-                    hipLaunchKernelGGL(k_trsm_panel, dim3((M - r0 + 63) / 64), 256, 0, sp, W + (size_t)k * ld,
-                                       ld, r0, M, kb, Fp);
-                if (r0 < kme)  // rest of this middle block: rows [r0, M) x cols [r0, kme), K = kb
-                    launch_gemm_nt(sp, W + (size_t)r0 + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
-                                   W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, kme - r0, kb, 1);
-            }
-            if (kme < ke)  // rest of the outer block: rows [kme, M) x cols [kme, ke), K = kme - km
-                launch_gemm_nt(sp, W + (size_t)kme + (size_t)km * ld, ld, W + (size_t)kme + (size_t)km * ld, ld,
-                               W + (size_t)kme + (size_t)kme * ld, ld, M - kme, ke - kme, kme - km, 1);
-        }
-        if (la) {
-            hipEventRecord(c->evP, sp);
-            hipStreamWaitEvent(sm, c->evP, 0);
-        } else {
-            kt_end(c, 2, 0.0, sm);
-        }
-        // ---- trailing updates with the whole outer block, K = ke - ko
-        const int r0 = ke;
-        if (r0 >= M || r0 >= ncol) continue;
-        const int K = ke - ko;
-        const double *P = W + (size_t)r0 + (size_t)ko * ld;
-        int n1 = 0;
-        if (la && ke < nfac) {
-            n1 = (nfac - ke < NBO) ? nfac - ke : NBO;  // columns of the next outer block
-            launch_gemm_nt(sm, P, ld, P, ld, W + (size_t)r0 + (size_t)r0 * ld, ld, M - r0, n1, K, 1);
-            hipEventRecord(c->evU, sm);
-            hipStreamWaitEvent(sp, c->evU, 0);
-        }
-        const int r1 = r0 + n1;
-        if (r1 < M && r1 < ncol) {
-            const double mt = (double)(ncol - r1), extra = (double)(M - ncol);
-            kt_begin(c, 1, sm);
-            launch_syrk_lower(sm, W + (size_t)r1 + (size_t)ko * ld, ld, W + (size_t)r1 + (size_t)r1 * ld, ld,
-                              M - r1, ncol - r1, K);
+    const bool la = c->lookahead > 0 && c->pstream && nfac > NBO && NBO / GPMI_NB <= GPMI_FPACK_SLOTS;
+    if (!la) {
+        hipStream_t s = c->stream;
+        for (int ko = 0; ko < nfac; ko += NBO) {
+            const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
+            kt_begin(c, 2, s);
+            panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, NBO, 0, M, true, s);
+            kt_end(c, 2, 0.0, s);
+            if (ke >= M || ke >= ncol) continue;
+            const double mt = (double)(ncol - ke), extra = (double)(M - ncol);
+            kt_begin(c, 1, s);
+            launch_syrk_lower(s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld, M - ke,
+                              ncol - ke, ke - ko, c->d_ctr, c->ncu);
             // algorithmic flops: lower triangle (incl. diagonal) of the square part + extra rows
-            kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)K, sm);
+            kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(ke - ko), s);
         }
-    }
-    if (masked) {
-        hipEventRecord(c->evM, sm);
-        hipStreamWaitEvent(c->stream, c->evM, 0);
+    } else {
+        // One-block look-ahead (opt-in).  The panel phase is split by rows:
+        //   Diag(s) : the NBO x NBO diagonal block -- 8 x (potrf_diag, narrow solve, narrow update),
+        //             a pure latency chain of few-workgroup kernels          -> priority stream
+        //   Rows(s) : the panel solve for the rows below it -- wide kernels   -> bulk stream
+        // and the trailing update with block s into
+        //   U1a(s)  : the next diagonal block (all Diag(s+1) needs)           -> bulk stream
+        //   U1b(s), U2(s) : the rest                                          -> bulk stream
+        // Diag(s+1) runs on a few CUs while U1b(s) and U2(s) fill the chip.  The bulk stream may
+        // be CU-masked (cu_reserve): potrf_diag needs a whole CU's LDS and would otherwise wait
+        // for one to drain by chance while SYRK workgroups refill every slot that frees up.
+        const bool masked = c->cu_reserve > 0 && c->mstream;
+        hipStream_t sb = masked ? c->mstream : c->stream, sc = c->pstream;
+        hipEventRecord(c->evM, c->stream);
+        if (masked) hipStreamWaitEvent(sb, c->evM, 0);
+        hipStreamWaitEvent(sc, c->evM, 0);
+        {
+            const int ke0 = NBO < nfac ? NBO : nfac;
+            panel_rows(c, W, ld, d_info, Fpack_all, 0, ke0, NBO, 0, ke0, true, sc);
+            hipEventRecord(c->evP, sc);
+        }
+        for (int ko = 0; ko < nfac; ko += NBO) {
+            const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
+            const int K = ke - ko;
+            hipStreamWaitEvent(sb, c->evP, 0);  // Diag(s) done
+            if (ke < M) panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, NBO, ke, M, false, sb);
+            if (ke >= M || ke >= ncol) continue;
+            if (ke < nfac) {
+                const int ke2 = (ke + NBO < nfac) ? ke + NBO : nfac;
+                launch_syrk_lower(sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
+                                  ke2 - ke, ke2 - ke, K, c->d_ctr, c->ncu);
+                hipEventRecord(c->evU, sb);
+                hipStreamWaitEvent(sc, c->evU, 0);
+                panel_rows(c, W, ld, d_info, Fpack_all, ke, ke2, NBO, 0, ke2, true, sc);
+                hipEventRecord(c->evP, sc);
+                if (ke2 < M)
+                    launch_gemm_nt(sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ko * ld, ld,
+                                   W + (size_t)ke2 + (size_t)ke * ld, ld, M - ke2, ke2 - ke, K, 1);
+                if (ke2 < M && ke2 < ncol)
+                    launch_syrk_lower(sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke2 + (size_t)ke2 * ld,
+                                      ld, M - ke2, ncol - ke2, K, c->d_ctr, c->ncu);
+            } else {  // last factored block: Schur complement / augmented rows
+                launch_syrk_lower(sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
+                                  M - ke, ncol - ke, K, c->d_ctr, c->ncu);
+            }
+        }
+        hipEventRecord(c->evM, sb);
+        if (masked) hipStreamWaitEvent(c->stream, c->evM, 0);
+        hipEventRecord(c->evU, sc);
+        hipStreamWaitEvent(c->stream, c->evU, 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "potrf launch failed: %s", hipGetErrorString(e));

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -71,6 +72,94 @@ void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t st)
 
 extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9);
 
+// ---- stream calibration -------------------------------------------------------
+// Kernels of two HIP streams overlap freely only if the streams' hardware queues are served by
+// different command-processor pipes (MI355X: 4 per process as observed; queues on one pipe are
+// time-sliced in ~56 us quanta, which triples the latency of every small kernel that runs next
+// to another queue's trailing update).  Neither HIP nor HSA tells which pipe a queue is on, so
+// it is measured: a long many-round kernel on stream a, a one-workgroup kernel on stream b and
+// the time until b's kernel is done -- ~15 us if the two queues dispatch concurrently, a time
+// slice or the whole long kernel if not.  Candidates are dedicated queues: the CU-mask API gives
+// every stream its own hardware queue instead of one shared out of the runtime's pool.
+namespace {
+__global__ __launch_bounds__(256) void k_cal_long(int *sink, int spin)
+{
+    __shared__ int pad[18 * 1024];  // 72 KiB: two workgroups per CU, like the trailing update
+    pad[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    int acc = 0;
+    for (int i = 0; i < spin; ++i) {
+        __builtin_amdgcn_s_sleep(100);
+        acc += pad[(threadIdx.x + i) & 255];
+    }
+    if (acc == 0x7fffffff) sink[0] = acc;
+}
+__global__ void k_cal_short(int *sink)
+{
+    if (sink[1] == 0x7fffffff) sink[2] = 1;
+}
+}  // namespace
+
+static int streams_concurrent(gpmi_ctx *c, hipStream_t a, hipStream_t b, bool *conc)
+{
+    int *sink = c->d_info + 8;
+    int votes = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIPCHK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_cal_long, dim3(4096), 256, 0, a, sink, 24);
+        hipLaunchKernelGGL(k_cal_short, dim3(1), 64, 0, b, sink);
+        HIPCHK(hipStreamSynchronize(b));
+        const auto t1 = std::chrono::steady_clock::now();
+        HIPCHK(hipDeviceSynchronize());
+        const auto t2 = std::chrono::steady_clock::now();
+        const double tb = std::chrono::duration<double>(t1 - t0).count(), ta = std::chrono::duration<double>(t2 - t0).count();
+        if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] probe: short %.0f us, long %.0f us\n", 1e6 * tb, 1e6 * ta);
+        votes += (tb < 45e-6 && tb < 0.25 * ta);
+    }
+    *conc = votes >= 2;
+    return 0;
+}
+
+static int full_mask_stream(gpmi_ctx *c, hipStream_t *out)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, c->device));
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
+    if (prop.multiProcessorCount % 32) mask[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    HIPCHK(hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()));
+    hipLaunchKernelGGL(k_cal_short, dim3(1), 64, 0, *out, c->d_info + 8);  // binds the hardware queue
+    HIPCHK(hipStreamSynchronize(*out));
+    return 0;
+}
+
+// up to 4 dedicated streams that are pairwise concurrent (one per pipe)
+static int calibrate_streams(gpmi_ctx *c)
+{
+    if (c->nq > 0) return 0;
+    int nq = 0, rc;
+    for (int i = 0; i < 10 && nq < 4; ++i) {
+        hipStream_t cand;
+        const char *kind = getenv("GPMI_CAL_KIND");  // experiment: 1 = dedicated (CU-mask API) queues
+        if (kind && atoi(kind) == 1) {
+            if ((rc = full_mask_stream(c, &cand))) return rc;
+        } else {
+            HIPCHK(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+            hipLaunchKernelGGL(k_cal_short, dim3(1), 64, 0, cand, c->d_info + 8);  // binds the hardware queue
+            HIPCHK(hipStreamSynchronize(cand));
+        }
+        bool ok = true;
+        for (int k = 0; k < nq && ok; ++k)
+            if ((rc = streams_concurrent(c, c->qstream[k], cand, &ok))) return rc;
+        if (ok) c->qstream[nq++] = cand;
+        else HIPCHK(hipStreamDestroy(cand));
+    }
+    c->nq = nq;
+    if (getenv("GPMI_DEBUG")) fprintf(stderr, "[gpmi] stream calibration: %d concurrent dispatch streams\n", nq);
+    return 0;
+}
+
 // (re)create the CU-masked trailing-update stream for the current cu_reserve / mode
 int ensure_mstream(gpmi_ctx *c)
 {
@@ -90,6 +179,17 @@ int ensure_mstream(gpmi_ctx *c)
     }
     HIPCHK(hipExtStreamCreateWithCUMask(&c->mstream, (uint32_t)words, mask.data()));
     return 0;
+}
+
+// streams of the look-ahead: priority stream for the diagonal-block chain (+ masked bulk stream)
+static int ensure_aux_streams(gpmi_ctx *c)
+{
+    if (!c->pstream) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, greatest));
+    }
+    return ensure_mstream(c);
 }
 
 // ---- context ---------------------------------------------------------------
@@ -129,26 +229,27 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, greatest));
         HIPCHK(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evU, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
-        c->lookahead = -1;  // auto: on for large factorisations (see launch_potrf_partial)
-        c->cu_reserve = 8;
+        c->lookahead = -1;  // -1 / 0: off (default), 1: on (see launch_potrf_partial)
+        // Auxiliary streams (priority panel stream, optional CU-masked bulk stream) exist only while
+        // look-ahead is switched on: every extra hardware queue shifts the queue -> pipe layout
+        // the grid lanes depend on, and CU-masked queues dispatch markedly slower than plain ones.
+        c->cu_reserve = 0;
         c->cu_mask_mode = 1;
+        c->calibrate = 1;
     }
-    HIPCHK(hipMalloc((void **)&c->Fpack, GPMI_FPACK * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&c->Fpack, (size_t)GPMI_FPACK_SLOTS * GPMI_FPACK * sizeof(double)));
     HIPCHK(hipMalloc((void **)&c->d_info, 64));
+    HIPCHK(hipMalloc((void **)&c->d_ctr, 64));
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, 64, c->own_stream));
+    HIPCHK(hipStreamSynchronize(c->own_stream));
+    c->ncu = prop.multiProcessorCount;
     HIPCHK(hipMalloc((void **)&c->d_out, 64));
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-    {
-        int rc = ensure_mstream(c);
-        if (rc) return rc;
-    }
     *out = c;
     return 0;
 }
@@ -162,14 +263,17 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         hipFree(c->W);
         hipFree(c->Fpack);
         hipFree(c->d_info);
+        hipFree(c->d_ctr);
         hipFree(c->d_out);
         hipFree(c->scratch);
         for (int i = 0; i < 4; ++i) {
             hipFree(c->stage[i]);
             hipEventDestroy(c->ev[i]);
         }
-        hipStreamSynchronize(c->pstream);
-        hipStreamDestroy(c->pstream);
+        if (c->pstream) {
+            hipStreamSynchronize(c->pstream);
+            hipStreamDestroy(c->pstream);
+        }
         if (c->mstream) {
             hipStreamSynchronize(c->mstream);
             hipStreamDestroy(c->mstream);
@@ -179,6 +283,7 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         hipEventDestroy(c->evJoin);
         for (int l = 0; l < 7; ++l)
             if (c->lane[l]) gpmi_destroy(c->lane[l]);
+        for (int q = 0; q < c->nq; ++q) hipStreamDestroy(c->qstream[q]);
         hipEventDestroy(c->evP);
         hipEventDestroy(c->evU);
         hipStreamDestroy(c->own_stream);
@@ -220,7 +325,7 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         }
         if (!strcmp(name, "cu_reserve")) c->cu_reserve = value;
         else c->cu_mask_mode = value;
-        return ensure_mstream(c);
+        return c->lookahead > 0 ? ensure_mstream(c) : 0;
     }
     if (!strcmp(name, "rect_auto")) {
         extern int g_rect_auto;
@@ -230,6 +335,17 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     if (!strcmp(name, "stagger")) {
         extern int g_stagger;
         g_stagger = value;
+        return 0;
+    }
+    if (!strcmp(name, "diag_waves")) {
+        extern int g_diag_waves;
+        if (value != 4 && value != 5) return gpmi_fail(GPMI_EARG, "diag_waves must be 4 or 5");
+        g_diag_waves = value;
+        return 0;
+    }
+    if (!strcmp(name, "syrk_persist")) {
+        extern int g_syrk_persist;
+        g_syrk_persist = value;
         return 0;
     }
     if (!strcmp(name, "syrk_order")) {
@@ -242,6 +358,27 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         g_gemm_variant = value;
         return 0;
     }
+    if (!strcmp(name, "debug_topology")) {  // prints which of the context's streams dispatch concurrently
+        hipStream_t st[4] = {c->stream, c->own_stream, c->pstream, c->mstream};
+        const char *nm[4] = {"stream", "own", "panel", "masked"};
+        for (int a = 0; a < 4; ++a) {
+            fprintf(stderr, "%8s:", nm[a]);
+            for (int b = 0; b < 4; ++b) {
+                bool conc = false;
+                if (a != b && st[a] && st[b] && st[a] != st[b]) {
+                    int rc = streams_concurrent(c, st[a], st[b], &conc);
+                    if (rc) return rc;
+                }
+                fprintf(stderr, " %c", (a == b || st[a] == st[b]) ? '-' : (conc ? 'c' : 'S'));
+            }
+            fprintf(stderr, "\n");
+        }
+        return 0;
+    }
+    if (!strcmp(name, "calibrate")) {
+        c->calibrate = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "lane_lookahead")) {
         c->lane_lookahead = value != 0;
         return 0;
@@ -251,9 +388,9 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->grid_lanes = value;
         return 0;
     }
-    if (!strcmp(name, "lookahead")) {  // 0 off, 1 on, -1 auto
+    if (!strcmp(name, "lookahead")) {  // 1 on; 0 / -1 off (default)
         c->lookahead = value;
-        return 0;
+        return value > 0 ? ensure_aux_streams(c) : 0;
     }
     if (!strcmp(name, "timing")) {
         c->timing = value != 0;
@@ -300,6 +437,7 @@ extern "C" int gpmi_reserve(gpmi_ctx *c, int n_max)
         if (!c->lane[l - 1] && (rc = gpmi_create(&c->lane[l - 1], c->device))) return rc;
         if ((rc = reserve_ws(c->lane[l - 1], n_max + 1, n_max + 1))) return rc;
     }
+    if (lanes > 1 && c->calibrate && (rc = calibrate_streams(c))) return rc;
     return 0;
 }
 
@@ -637,38 +775,53 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
         gpmi_ctx *lc = c->lane[l - 1];
         lc->nb_outer = c->nb_outer;
         lc->lookahead = c->lane_lookahead;  // default 0: concurrent lanes already fill the panel phases
-        if (lc->cu_reserve != c->cu_reserve) {  // same CU reservation as the parent
-            if (lc->mstream) {
-                HIPCHK(hipStreamSynchronize(lc->mstream));
-                HIPCHK(hipStreamDestroy(lc->mstream));
-                lc->mstream = nullptr;
-            }
-            lc->cu_reserve = c->cu_reserve;
-            int rc = ensure_mstream(lc);
+        if (c->lane_lookahead) {
+            int rc = ensure_aux_streams(lc);
             if (rc) return rc;
         }
     }
-    const int la_saved = c->lookahead;
-    if (lanes > 1) c->lookahead = c->lane_lookahead;
-    if (lanes > 1) {
-        HIPCHK(hipEventRecord(c->evFork, c->stream));
-        for (int l = 1; l < lanes; ++l) HIPCHK(hipStreamWaitEvent(c->lane[l - 1]->stream, c->evFork, 0));
+    if (lanes > 1 && c->lane_lookahead) {
+        int rc = ensure_aux_streams(c);
+        if (rc) return rc;
     }
-    for (int g = 0; g < G; ++g) {
-        SeParams p;
-        int rc = fill_params(&p, D, alpha[g], &rho[g], 1);
-        gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
-        if (!rc) rc = logml_core(lc, dX, n, ldx, dy, p, sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g);
-        if (rc) {
-            c->lookahead = la_saved;
-            return rc;
+    if (lanes > 1 && c->calibrate) {
+        int rc = calibrate_streams(c);
+        if (rc) return rc;
+    }
+    const int la_saved = c->lookahead;
+    hipStream_t const caller = c->stream;
+    if (lanes > 1) {
+        // lanes fork from / join into the caller's stream; with calibration every lane (lane 0
+        // is this context itself) runs on a stream of its own hardware pipe
+        c->lookahead = c->lane_lookahead;
+        const bool useq = c->calibrate && c->nq > 1;
+        hipEventRecord(c->evFork, caller);
+        for (int l = 0; l < lanes; ++l) {
+            gpmi_ctx *lc = l ? c->lane[l - 1] : c;
+            lc->stream = useq ? c->qstream[l % c->nq] : (l ? lc->own_stream : caller);
+            if (lc->stream != caller) hipStreamWaitEvent(lc->stream, c->evFork, 0);
         }
     }
-    c->lookahead = la_saved;
-    for (int l = 1; l < lanes; ++l) {
-        HIPCHK(hipEventRecord(c->lane[l - 1]->evJoin, c->lane[l - 1]->stream));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->lane[l - 1]->evJoin, 0));
+    int rc = 0;
+    for (int g = 0; g < G && !rc; ++g) {
+        SeParams p;
+        rc = fill_params(&p, D, alpha[g], &rho[g], 1);
+        gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
+        if (!rc) rc = logml_core(lc, dX, n, ldx, dy, p, sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g);
     }
+    c->lookahead = la_saved;
+    if (lanes > 1) {
+        for (int l = 0; l < lanes; ++l) {
+            gpmi_ctx *lc = l ? c->lane[l - 1] : c;
+            if (lc->stream != caller) {
+                hipEventRecord(lc->evJoin, lc->stream);
+                hipStreamWaitEvent(caller, lc->evJoin, 0);
+            }
+            lc->stream = l ? lc->own_stream : caller;
+        }
+    }
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -916,7 +1069,8 @@ extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
 
 // Stand-alone trailing-update launch on synthetic data: C (m x m, lower) -= P P^T, P m x k.
 // `reps` back-to-back launches timed with HIP events; ms = average per launch.
-void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k);
+void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
+                       int ncu);
 __global__ void k_fill(double *p, size_t n, double scale)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -936,9 +1090,9 @@ extern "C" int gpmi_probe_syrk(gpmi_ctx *c, int m, int k, int reps, double *ms)
     if ((rc = stage_buf(c, 3, ld * (size_t)(k + 1) * sizeof(double), &P))) return rc;
     hipLaunchKernelGGL(k_fill, dim3(2048), 256, 0, c->stream, c->W, ld * (size_t)m, 1.0);
     hipLaunchKernelGGL(k_fill, dim3(2048), 256, 0, c->stream, P, ld * (size_t)k, 1e-3);
-    launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k);
+    launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k, c->d_ctr, c->ncu);
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    for (int r = 0; r < reps; ++r) launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k);
+    for (int r = 0; r < reps; ++r) launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k, c->d_ctr, c->ncu);
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());

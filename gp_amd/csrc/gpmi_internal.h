@@ -6,6 +6,7 @@
 
 #define GPMI_NB 128          // inner panel width == diagonal-block order
 #define GPMI_FPACK 9216      // doubles in one packed panel-factor buffer (36 tiles x 256)
+#define GPMI_FPACK_SLOTS 16   // per-context ring of such buffers: one per 128-column panel of an outer block
 #define GPMI_MAXD 8          // dimensions the register-resident fast path handles
 #define GPMI_MAXD_BIG 64     // dimensions the generic path handles (inverse length-scales in kernel arguments)
 
@@ -30,6 +31,8 @@ struct gpmi_ctx {
     double *scratch;         // small device scratch (results, staging)
     size_t scratch_bytes;
     int *d_info;
+    int *d_ctr;              // zeroed counters of the persistent trailing-update kernel (tile, retired, early exits)
+    int ncu;                 // compute units of the device
     double *d_out;           // 3 doubles
     // generic device staging buffers for the host-pointer API
     double *stage[4];
@@ -55,6 +58,12 @@ struct gpmi_ctx {
     int lane_lookahead;      // panel look-ahead inside each lane of a multi-lane grid (default off)
     gpmi_ctx *lane[7];
     hipEvent_t evFork, evJoin;
+    // Dispatch streams on distinct command-processor pipes (root context), found by probing:
+    // kernels of two queues overlap freely only if the queues sit on different pipes
+    // (see calibrate_streams in gpmi_api.hip).
+    hipStream_t qstream[4];
+    int nq;                  // number of mutually concurrent streams found (0 = not probed yet)
+    int calibrate;           // 1: run grid lanes on qstream[]; 0: on the lanes' plain streams
 };
 
 // event-pair recorder; begin/end bracket one launch on the context's stream
