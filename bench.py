@@ -235,7 +235,7 @@ def main():
                       "whole grid" % (n, D),
                 "c5": "c5: derivative joint [y, y'] covariance, N=%d (matrix order %d), build + fp64 Cholesky "
                       "+ solve + log-det" % (n, 2 * n)}[args.workload],
-                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1, "nb_outer": args.nb_outer or "auto(1024)",
+                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1, "nb_outer": args.nb_outer or "auto(%d)" % (lambda nf: 1024 if nf >= 12288 else 512 if nf >= 6144 else 256)(2 * n if args.workload == "c5" else n),
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
             "grid_lanes": args.grid_lanes or "auto(4)",
