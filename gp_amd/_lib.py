@@ -22,6 +22,8 @@ SYMBOLS = (
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
+    "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev",
+    "gpmi_interp_free",
     "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
 )
 
@@ -246,6 +248,45 @@ class Context:
         L = np.empty((n, n), order="F"); dL = np.empty((n, n), order="F")
         _chk(self._lib.gpmi_rbf_cov_chol(self._h, _p(x), n, _d(l), _p(L), max(n, 1), _p(dL), max(n, 1)))
         return L, dL
+
+    # ---- Cholesky-factor interpolation over the length-scale ------------------
+    def interp_build(self, x, lp):
+        """Table of L(lp[p]), dL/dl(lp[p]) built and kept on the device (test_interpolate.R:9-19)."""
+        x = _vec(x); lp = _vec(lp)
+        _chk(self._lib.gpmi_interp_build(self._h, _p(x), x.size, _p(lp), lp.size))
+        self._itp_n = x.size
+
+    def interp_load(self, lp, Ls, dLdls):
+        """Upload a caller-supplied table: sequences of P n x n matrices."""
+        lp = _vec(lp)
+        n = np.asarray(Ls[0]).shape[0]
+        A = np.ascontiguousarray(np.stack([np.asfortranarray(np.asarray(a, dtype=np.float64)).ravel(order="F") for a in Ls]))
+        B = np.ascontiguousarray(np.stack([np.asfortranarray(np.asarray(a, dtype=np.float64)).ravel(order="F") for a in dLdls]))
+        if A.shape != (lp.size, n * n) or B.shape != A.shape:
+            raise GpmiError(-1, "lp, Ls and dLdls disagree on the table shape")
+        _chk(self._lib.gpmi_interp_load(self._h, _p(lp), lp.size, _p(A), _p(B), n, n))
+        self._itp_n = n
+
+    def approx_L(self, l):
+        n = getattr(self, "_itp_n", 0)
+        out = np.empty((n, n), order="F")
+        _chk(self._lib.gpmi_approx_L(self._h, _d(l), _p(out), max(n, 1)))
+        return out
+
+    def approx_Lz(self, l, z):
+        z = _vec(z)
+        if z.size != getattr(self, "_itp_n", -1):
+            raise GpmiError(-1, "z must have the table's order")
+        f = np.empty(z.size)
+        _chk(self._lib.gpmi_approx_Lz(self._h, _d(l), _p(z), _p(f)))
+        return f
+
+    def approx_Lz_dev(self, l, dz_ptr, df_ptr):
+        _chk(self._lib.gpmi_approx_Lz_dev(self._h, _d(l), C.c_void_p(dz_ptr), C.c_void_p(df_ptr)))
+
+    def interp_free(self):
+        _chk(self._lib.gpmi_interp_free(self._h))
+        self._itp_n = 0
 
     def gp_condition(self, t, ts, y, alpha, l, s2, jitter, kindK, kindS, kindSS, flags=FULL):
         t = _vec(t); ts = _vec(ts); y = _vec(y)

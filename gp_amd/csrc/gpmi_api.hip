@@ -264,6 +264,10 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         hipFree(c->Fpack);
         hipFree(c->d_info);
         hipFree(c->d_ctr);
+        hipFree(c->itp_L);
+        hipFree(c->itp_dL);
+        hipFree(c->itp_part);
+        free(c->itp_lp);
         hipFree(c->d_out);
         hipFree(c->scratch);
         for (int i = 0; i < 4; ++i) {
@@ -937,25 +941,22 @@ __global__ void k_rbf_dsigma(const double *__restrict__ x, int n, double l, doub
     }
 }
 
-extern "C" int gpmi_rbf_cov_chol(gpmi_ctx *c, const double *x, int n, double l, double *L, int ldl,
-                                 double *dLdl, int lddl)
+// device core: x resident in dx; on return (stream order) Lc holds L (zero upper) and S holds dL/dl,
+// both n x n with leading dimension ldd in the context's staging buffers 3 and 1
+static int rbf_cov_chol_core(gpmi_ctx *c, const double *dx, int n, double l, double **Lc_out, double **S_out, int *ldd_out)
 {
-    ENTER(c);
-    if (n <= 0 || !x || !L || !dLdl || ldl < n || lddl < n || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
     int rc;
     if ((rc = reserve_ws(c, n, n))) return rc;
     const size_t ld = (size_t)c->ld;
     const int ldd = ((n + 15) / 16) * 16 + 16;
     const size_t msz = (size_t)ldd * (n + 1) * sizeof(double);
     const int npan = (n + GPMI_NB - 1) / GPMI_NB;
-    double *dx, *S, *S2, *Lc, *Fall;
-    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
+    double *S, *S2, *Lc, *Fall;
     if ((rc = stage_buf(c, 1, msz, &S))) return rc;
     if ((rc = stage_buf(c, 2, msz, &S2))) return rc;
     if ((rc = stage_buf(c, 3, msz, &Lc))) return rc;
     if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
     hipStream_t s = c->stream;
-    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
     // Sigma (+1e-10 jitter, covariance.cpp:23-25) -> L
     SeParams p;
@@ -972,12 +973,171 @@ extern "C" int gpmi_rbf_cov_chol(gpmi_ctx *c, const double *x, int n, double l, 
     launch_phi_mask(s, S2, (size_t)ldd, n);                                                       // Phi^T (upper)
     launch_gemm_nt(s, Lc, (size_t)ldd, S2, (size_t)ldd, S, (size_t)ldd, n, n, n, 0);              // S = L Phi
     HIPCHK(hipGetLastError());
+    *Lc_out = Lc;
+    *S_out = S;
+    *ldd_out = ldd;
+    return 0;
+}
+
+extern "C" int gpmi_rbf_cov_chol(gpmi_ctx *c, const double *x, int n, double l, double *L, int ldl,
+                                 double *dLdl, int lddl)
+{
+    ENTER(c);
+    if (n <= 0 || !x || !L || !dLdl || ldl < n || lddl < n || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc, ldd;
+    double *dx, *Lc, *S;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = rbf_cov_chol_core(c, dx, n, l, &Lc, &S, &ldd))) return rc;
     int info = 0;
     HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
     if ((rc = d2h_matrix(c, Lc, (size_t)ldd, n, n, L, ldl))) return rc;
     if ((rc = d2h_matrix(c, S, (size_t)ldd, n, n, dLdl, lddl))) return rc;
     HIPCHK(hipStreamSynchronize(s));
     return info;
+}
+
+// ---- Cholesky-factor interpolation over the length-scale ---------------------------
+extern "C" int gpmi_interp_free(gpmi_ctx *c)
+{
+    ENTER(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(c->itp_L);
+    hipFree(c->itp_dL);
+    hipFree(c->itp_part);
+    free(c->itp_lp);
+    c->itp_L = c->itp_dL = c->itp_part = nullptr;
+    c->itp_lp = nullptr;
+    c->itp_P = c->itp_n = 0;
+    return 0;
+}
+
+static int interp_alloc(gpmi_ctx *c, const double *lp, int P, int n)
+{
+    if (P < 2 || n <= 0 || !lp) return gpmi_fail(GPMI_EARG, "interpolation table needs P >= 2 length-scales");
+    for (int p = 0; p + 1 < P; ++p)
+        if (!(lp[p + 1] > lp[p])) return gpmi_fail(GPMI_EARG, "lp must be strictly increasing");
+    int rc = gpmi_interp_free(c);
+    if (rc) return rc;
+    c->itp_ld = (size_t)((n + 1) & ~1);
+    const size_t bytes = (size_t)P * c->itp_ld * n * sizeof(double);
+    if (hipMalloc((void **)&c->itp_L, bytes) != hipSuccess || hipMalloc((void **)&c->itp_dL, bytes) != hipSuccess ||
+        hipMalloc((void **)&c->itp_part, (size_t)hermite_mv_chunks(n) * n * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        gpmi_interp_free(c);
+        return gpmi_fail(GPMI_ENOMEM, "interpolation table of %d x %d x %d does not fit", P, n, n);
+    }
+    c->itp_lp = (double *)malloc(sizeof(double) * P);
+    if (!c->itp_lp) return gpmi_fail(GPMI_ENOMEM, "host allocation failed");
+    memcpy(c->itp_lp, lp, sizeof(double) * P);
+    c->itp_P = P;
+    c->itp_n = n;
+    return 0;
+}
+
+extern "C" int gpmi_interp_build(gpmi_ctx *c, const double *x, int n, const double *lp, int P)
+{
+    ENTER(c);
+    if (!x) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    if ((rc = interp_alloc(c, lp, P, n))) return rc;
+    double *dx;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    int first_bad = 0;
+    for (int p = 0; p < P; ++p) {
+        if (!(lp[p] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scales must be positive");
+        double *Lc, *S;
+        int ldd;
+        if ((rc = rbf_cov_chol_core(c, dx, n, lp[p], &Lc, &S, &ldd))) return rc;
+        launch_copy_matrix(s, Lc, (size_t)ldd, c->itp_L + (size_t)p * c->itp_ld * n, c->itp_ld, n, n, 0);
+        launch_copy_matrix(s, S, (size_t)ldd, c->itp_dL + (size_t)p * c->itp_ld * n, c->itp_ld, n, n, 0);
+        int info = 0;
+        HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (info && !first_bad) first_bad = info;
+    }
+    return first_bad;
+}
+
+extern "C" int gpmi_interp_load(gpmi_ctx *c, const double *lp, int P, const double *Ls, const double *dLdls,
+                                int n, int ld)
+{
+    ENTER(c);
+    if (!Ls || !dLdls || ld < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    if ((rc = interp_alloc(c, lp, P, n))) return rc;
+    for (int p = 0; p < P; ++p) {
+        HIPCHK(hipMemcpy2DAsync(c->itp_L + (size_t)p * c->itp_ld * n, c->itp_ld * sizeof(double),
+                                Ls + (size_t)p * ld * n, (size_t)ld * sizeof(double), (size_t)n * sizeof(double), n,
+                                hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpy2DAsync(c->itp_dL + (size_t)p * c->itp_ld * n, c->itp_ld * sizeof(double),
+                                dLdls + (size_t)p * ld * n, (size_t)ld * sizeof(double), (size_t)n * sizeof(double), n,
+                                hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// interval of the reference (covariance.cpp:57-61), clamped to the last one
+static int interp_interval(const gpmi_ctx *c, double l)
+{
+    int lidx = 0;
+    for (; lidx < c->itp_P - 1; ++lidx)
+        if (c->itp_lp[lidx + 1] >= l) break;
+    return lidx > c->itp_P - 2 ? c->itp_P - 2 : lidx;
+}
+
+extern "C" int gpmi_approx_L(gpmi_ctx *c, double l, double *out, int ldo)
+{
+    ENTER(c);
+    if (!c->itp_L) return gpmi_fail(GPMI_EARG, "no interpolation table (gpmi_interp_build / gpmi_interp_load first)");
+    const int n = c->itp_n;
+    if (!out || ldo < n || !(l == l)) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    double *dout;
+    const size_t ldd = (size_t)((n + 1) & ~1);
+    if ((rc = stage_buf(c, 1, ldd * n * sizeof(double), &dout))) return rc;
+    const int k = interp_interval(c, l);
+    const size_t msz = c->itp_ld * n;
+    launch_hermite_blend(c->stream, c->itp_L + k * msz, c->itp_L + (k + 1) * msz, c->itp_dL + k * msz,
+                         c->itp_dL + (k + 1) * msz, c->itp_ld, n, c->itp_lp[k], c->itp_lp[k + 1], l, dout, ldd);
+    if ((rc = d2h_matrix(c, dout, ldd, n, n, out, ldo))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_approx_Lz_dev(gpmi_ctx *c, double l, const double *dz, double *df)
+{
+    ENTER(c);
+    if (!c->itp_L) return gpmi_fail(GPMI_EARG, "no interpolation table (gpmi_interp_build / gpmi_interp_load first)");
+    if (!dz || !df || !(l == l)) return gpmi_fail(GPMI_EARG, "bad argument");
+    const int n = c->itp_n;
+    const int k = interp_interval(c, l);
+    const size_t msz = c->itp_ld * n;
+    HIPCHK(hipMemsetAsync(c->itp_part, 0, (size_t)hermite_mv_chunks(n) * n * sizeof(double), c->stream));
+    launch_hermite_mv(c->stream, c->itp_L + k * msz, c->itp_L + (k + 1) * msz, c->itp_dL + k * msz,
+                      c->itp_dL + (k + 1) * msz, c->itp_ld, n, c->itp_lp[k], c->itp_lp[k + 1], l, dz, c->itp_part, df);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_approx_Lz(gpmi_ctx *c, double l, const double *z, double *f)
+{
+    ENTER(c);
+    if (!c->itp_L) return gpmi_fail(GPMI_EARG, "no interpolation table (gpmi_interp_build / gpmi_interp_load first)");
+    if (!z || !f) return gpmi_fail(GPMI_EARG, "bad argument");
+    const int n = c->itp_n;
+    int rc;
+    double *dz;
+    if ((rc = stage_buf(c, 0, 2 * (size_t)n * sizeof(double), &dz))) return rc;
+    HIPCHK(hipMemcpyAsync(dz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = gpmi_approx_Lz_dev(c, l, dz, dz + n))) return rc;
+    HIPCHK(hipMemcpyAsync(f, dz + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 // ---- GP posterior ---------------------------------------------------------------

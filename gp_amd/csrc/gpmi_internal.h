@@ -56,6 +56,11 @@ struct gpmi_ctx {
     // points overlap -- one point's panel phase and SYRK tails run under another's bulk update
     int grid_lanes;          // 0 = auto
     int lane_lookahead;      // panel look-ahead inside each lane of a multi-lane grid (default off)
+    // Cholesky-factor interpolation table (gpmi_interp_*): P stacked n x itp_ld matrices each
+    double *itp_L, *itp_dL, *itp_part;
+    double *itp_lp;          // host copy of the P length-scales
+    int itp_P, itp_n;
+    size_t itp_ld;
     gpmi_ctx *lane[7];
     hipEvent_t evFork, evJoin;
     // Dispatch streams on distinct command-processor pipes (root context), found by probing:
@@ -98,6 +103,11 @@ void launch_copy_matrix(hipStream_t s, const double *src, size_t lds, double *ds
                         int rows, int cols, int mode);  // mode 0 full, 1 lower (upper zero), 2 lower->symmetric
 void launch_add_diag(hipStream_t s, double *A, size_t ld, int n, double v);
 void launch_transpose(hipStream_t s, const double *src, size_t lds, double *dst, size_t ldd, int rows, int cols);
+void launch_hermite_blend(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
+                          size_t ld, int n, double x1, double x2, double l, double *out, size_t ldo);
+void launch_hermite_mv(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
+                       size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f);
+int hermite_mv_chunks(int n);
 void launch_phi_mask(hipStream_t s, double *B, size_t ld, int n); // keep upper, halve diag, zero strict lower
 
 // ---- kernel launchers (chol_kernels.hip) -----------------------------------

@@ -275,6 +275,70 @@ __global__ __launch_bounds__(256) void k_phi_mask(double *B, size_t ld, int n)
 
 inline bool vec_ok(const void *p, size_t ld) { return ((uintptr_t)p % 16 == 0) && (ld % 2 == 0); }
 
+
+// ---------------------------------------------------------------------------
+// Cholesky-factor interpolation (covariance.cpp:49-96, cubic_interpolated_gp.hpp:38-73):
+// cubic Hermite blend of two factors and their length-scale tangents, element by element, in
+// the reference's operation order.  HBM-bound: 4 matrices read (lower triangles).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double hermite(double y1, double y2, double k1, double k2, double dx, double t)
+{
+    const double a = k1 * dx - (y2 - y1);
+    const double b = -k2 * dx + (y2 - y1);
+    return (1 - t) * y1 + t * y2 + t * (1 - t) * (a * (1 - t) + b * t);
+}
+
+__global__ __launch_bounds__(256) void k_hermite_blend(const double *__restrict__ L1, const double *__restrict__ L2,
+                                                       const double *__restrict__ D1, const double *__restrict__ D2,
+                                                       size_t ld, int n, double dx, double t,
+                                                       double *__restrict__ out, size_t ldo)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= n) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j >= n) break;
+        const size_t o = (size_t)i + (size_t)j * ld;
+        out[(size_t)i + (size_t)j * ldo] = (j <= i) ? hermite(L1[o], L2[o], D1[o], D2[o], dx, t) : 0.0;
+    }
+}
+
+// f = blend(l) z without storing the blend: thread = row, blockIdx.y = chunk of HMV_CW columns;
+// partial row sums go to part[chunk][row] and are added in ascending chunk order by
+// k_hermite_mv_sum (fixed order: results do not depend on scheduling).
+constexpr int HMV_CW = 128;
+__global__ __launch_bounds__(256) void k_hermite_mv(const double *__restrict__ L1, const double *__restrict__ L2,
+                                                    const double *__restrict__ D1, const double *__restrict__ D2,
+                                                    size_t ld, int n, double dx, double t,
+                                                    const double *__restrict__ z, double *__restrict__ part)
+{
+    __shared__ double sz[HMV_CW];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * HMV_CW;
+    if (j0 > blockIdx.x * 256 + 255) return;  // chunk entirely right of this row block's diagonal: stays zero (part is pre-zeroed)
+    if (threadIdx.x < HMV_CW) sz[threadIdx.x] = (j0 + threadIdx.x < n) ? z[j0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (i >= n) return;
+    const int jend = (i + 1 < j0 + HMV_CW) ? i + 1 : j0 + HMV_CW;  // columns j <= i
+    double acc = 0.0;
+    for (int j = j0; j < jend; ++j) {
+        const size_t o = (size_t)i + (size_t)j * ld;
+        acc += hermite(L1[o], L2[o], D1[o], D2[o], dx, t) * sz[j - j0];
+    }
+    part[(size_t)blockIdx.y * n + i] = acc;
+}
+
+__global__ void k_hermite_mv_sum(const double *__restrict__ part, int n, int nchunks, double *__restrict__ f)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    const int cmax = i / HMV_CW;  // chunks right of the diagonal hold nothing for this row
+    for (int c = 0; c <= cmax && c < nchunks; ++c) acc += part[(size_t)c * n + i];
+    f[i] = acc;
+}
 }  // namespace
 
 void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
@@ -357,4 +421,25 @@ void launch_phi_mask(hipStream_t s, double *B, size_t ld, int n)
     if (n <= 0) return;
     dim3 grid((n + 63) / 64, (n + 15) / 16);
     hipLaunchKernelGGL(k_phi_mask, grid, 256, 0, s, B, ld, n);
+}
+
+void launch_hermite_blend(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
+                          size_t ld, int n, double x1, double x2, double l, double *out, size_t ldo)
+{
+    if (n <= 0) return;
+    const double t = (l - x1) / (x2 - x1);
+    hipLaunchKernelGGL(k_hermite_blend, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, L1, L2, D1, D2, ld, n, x2 - x1, t,
+                       out, ldo);
+}
+
+int hermite_mv_chunks(int n) { return (n + HMV_CW - 1) / HMV_CW; }
+
+void launch_hermite_mv(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
+                       size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f)
+{
+    if (n <= 0) return;
+    const double t = (l - x1) / (x2 - x1);
+    const int nch = hermite_mv_chunks(n);
+    hipLaunchKernelGGL(k_hermite_mv, dim3((n + 255) / 256, nch), 256, 0, s, L1, L2, D1, D2, ld, n, x2 - x1, t, z, part);
+    hipLaunchKernelGGL(k_hermite_mv_sum, dim3((n + 255) / 256), 256, 0, s, part, n, nch, f);
 }

@@ -162,6 +162,25 @@ int gpmi_joint_logml_dev(gpmi_ctx *ctx, const double *dt, int n, const double *d
 int gpmi_rbf_cov_chol(gpmi_ctx *ctx, const double *x, int n, double l, double *L, int ldl,
                       double *dLdl, int lddl);
 
+/* ---- Cholesky-factor interpolation over the length-scale ---------------
+ * Table of P factors L(lp[p]) and tangents dL/dl(lp[p]) kept in HBM (2 P n^2 doubles), then
+ * piecewise cubic Hermite blends at any l.  Interval rule of the reference: the first p with
+ * lp[p+1] >= l (clamped to the last interval, where the reference reads past the end).
+ *   gpmi_interp_build : the table test_interpolate.R:9-19 builds with P calls of rbf_cov_chol
+ *   gpmi_interp_load  : a caller-supplied table (P stacked n x n column-major matrices, leading
+ *                       dimension ld, matrix p at Ls + p*ld*n) -- the `Ls`, `dLdls` data of
+ *                       models/cubic_interpolated_gp.stan:11-12
+ *   gpmi_approx_L     : covariance.cpp:49-96 (lower triangle blended, zeros above)
+ *   gpmi_approx_Lz    : models/cubic_interpolated_gp.hpp:38-73, f = approx_L(l) z, fused (the
+ *                       blended matrix is never stored: 4 n^2/2 doubles read per call)      */
+int gpmi_interp_build(gpmi_ctx *ctx, const double *x, int n, const double *lp, int P);
+int gpmi_interp_load(gpmi_ctx *ctx, const double *lp, int P, const double *Ls, const double *dLdls,
+                     int n, int ld);
+int gpmi_approx_L(gpmi_ctx *ctx, double l, double *out, int ldo);
+int gpmi_approx_Lz(gpmi_ctx *ctx, double l, const double *z, double *f);
+int gpmi_approx_Lz_dev(gpmi_ctx *ctx, double l, const double *dz, double *df);
+int gpmi_interp_free(gpmi_ctx *ctx);
+
 /* ---- GP posterior (value / derivative) -------------------------------- */
 
 /* mn = Ks (K + s2 I)^-1 y,  Kn = Kss - Ks (K + s2 I)^-1 Ks^T + jitter I with

@@ -469,6 +469,22 @@ void orc_approx_L(double l, const double *lp, int P, const double *Ls, const dou
         }
 }
 
+/* approx_Lz(l, lp, Ls, dLdls, z) = v z with v the same Hermite blend formed as full matrices
+ * (the upper triangles of the factors are zero)        models/cubic_interpolated_gp.hpp:38-73
+ * (build_output, :33-35, adds a zero vector) */
+void orc_approx_Lz(double l, const double *lp, int P, const double *Ls, const double *dLs,
+                   int n, const double *z, double *f)
+{
+    double *v = (double *)malloc(sizeof(double) * (size_t)n * n);
+    orc_approx_L(l, lp, P, Ls, dLs, n, v, n);
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += A_(v, n, i, j) * z[j];
+        f[i] = acc;
+    }
+    free(v);
+}
+
 /* ------------------------------------------------------------------ */
 /* GP posterior of the state and of its time derivative               */
 /* ------------------------------------------------------------------ */

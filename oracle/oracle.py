@@ -173,6 +173,16 @@ def approx_L(l, lp, Ls, dLs):
     return out
 
 
+def approx_Lz(l, lp, Ls, dLs, z):
+    lp = np.ascontiguousarray(lp, dtype=np.float64); P = lp.size
+    n = Ls[0].shape[0]
+    Ls = np.ascontiguousarray(np.stack([np.asfortranarray(a).ravel(order="F") for a in Ls]))
+    dLs = np.ascontiguousarray(np.stack([np.asfortranarray(a).ravel(order="F") for a in dLs]))
+    z = np.ascontiguousarray(z, dtype=np.float64); f = np.empty(n)
+    lib().orc_approx_Lz(_d(l), _p(lp), P, _p(Ls), _p(dLs), n, _p(z), _p(f))
+    return f
+
+
 def p_Xn(tn, Xn, alpha, l, sigma):
     tn = np.ascontiguousarray(tn, dtype=np.float64); Xn = np.ascontiguousarray(Xn, dtype=np.float64)
     n = tn.size; mn = np.empty(n); Kn = np.empty((n, n), order="F")

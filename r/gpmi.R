@@ -50,6 +50,12 @@ gpmi_derivative_kernels_env <- local({
 # covariance.cpp:9-47
 rbf_cov_chol <- function(x1, l_) .Call("gpmi_R_rbf_cov_chol", as.double(x1), l_)
 
+# covariance.cpp:49-96 and models/cubic_interpolated_gp.hpp:38-73 (test_interpolate.R:9-19 builds the table)
+approx_L <- function(l, lp, Ls, dLdls) .Call("gpmi_R_approx_L", l, as.double(lp), Ls, dLdls)
+approx_Lz <- function(l, lp, Ls, dLdls, z) .Call("gpmi_R_approx_Lz", l, as.double(lp), Ls, dLdls, as.double(z))
+gp_interp_build <- function(x, lp) invisible(.Call("gpmi_R_interp_build", as.double(x), as.double(lp)))
+gp_interp_Lz <- function(l, z) .Call("gpmi_R_approx_Lz", l, numeric(0), NULL, NULL, as.double(z))
+
 # models/fit_hyperparameters.stan:18-32 as plain functions
 gp_log_marginal <- function(X, y, alpha, rho, sigma, jitter = 0)
   .Call("gpmi_R_logml", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)[1]

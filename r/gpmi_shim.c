@@ -13,6 +13,7 @@
  *   - one lazily created context per process (HIP does not survive fork():
  *     parallel::mclapply children get GPMI_EFORK -> re-create after a PID change).
  */
+#include <string.h>
 #include <R.h>
 #include <Rinternals.h>
 #include <unistd.h>
@@ -88,6 +89,62 @@ SEXP gpmi_R_rbf_cov_chol(SEXP x, SEXP l)
     UNPROTECT(4);
     check(rc);
     return out;
+}
+
+/* interp_build(x, lp): the device-resident table of L(lp[p]), dL/dl(lp[p]) that
+ * test_interpolate.R:9-19 builds with P calls of rbf_cov_chol */
+SEXP gpmi_R_interp_build(SEXP x, SEXP lp)
+{
+    check(gpmi_interp_build(ctx(), REAL(x), Rf_length(x), REAL(lp), Rf_length(lp)));
+    return R_NilValue;
+}
+
+/* approx_L(l, lp, Ls, dLdls): covariance.cpp:49-96.  Ls, dLdls are R lists of n x n matrices; only
+ * the two table entries around l travel to the device. */
+static int interval(double l, const double *lp, int P)
+{
+    int k = 0;
+    for (; k < P - 1; ++k)
+        if (lp[k + 1] >= l) break;
+    return k > P - 2 ? P - 2 : k;
+}
+static int load_pair(double l, SEXP lp, SEXP Ls, SEXP dLdls, int *n_out)
+{
+    int P = Rf_length(lp);
+    if (P < 2 || Rf_length(Ls) != P || Rf_length(dLdls) != P) return -1;
+    int k = interval(l, REAL(lp), P), n = Rf_nrows(VECTOR_ELT(Ls, k));
+    double *buf = (double *)R_alloc((size_t)4 * n * n, sizeof(double));  /* freed by R, also on error */
+    size_t m = (size_t)n * n;
+    memcpy(buf, REAL(VECTOR_ELT(Ls, k)), m * sizeof(double));
+    memcpy(buf + m, REAL(VECTOR_ELT(Ls, k + 1)), m * sizeof(double));
+    memcpy(buf + 2 * m, REAL(VECTOR_ELT(dLdls, k)), m * sizeof(double));
+    memcpy(buf + 3 * m, REAL(VECTOR_ELT(dLdls, k + 1)), m * sizeof(double));
+    double lp2[2] = {REAL(lp)[k], REAL(lp)[k + 1]};
+    *n_out = n;
+    return gpmi_interp_load(ctx(), lp2, 2, buf, buf + 2 * m, n, n);
+}
+SEXP gpmi_R_approx_L(SEXP l, SEXP lp, SEXP Ls, SEXP dLdls)
+{
+    int n = 0;
+    check(load_pair(Rf_asReal(l), lp, Ls, dLdls, &n));
+    SEXP out = PROTECT(Rf_allocMatrix(REALSXP, n, n));
+    int rc = gpmi_approx_L(ctx(), Rf_asReal(l), REAL(out), n);
+    UNPROTECT(1);
+    check(rc);
+    return out;
+}
+
+/* approx_Lz(l, lp, Ls, dLdls, z): models/cubic_interpolated_gp.hpp:38-73; with Ls = NULL the table of
+ * gpmi_R_interp_build is used (one call per leapfrog step, nothing but z crosses PCIe) */
+SEXP gpmi_R_approx_Lz(SEXP l, SEXP lp, SEXP Ls, SEXP dLdls, SEXP z)
+{
+    int n = Rf_length(z);
+    if (!Rf_isNull(Ls)) check(load_pair(Rf_asReal(l), lp, Ls, dLdls, &n));
+    SEXP f = PROTECT(Rf_allocVector(REALSXP, n));
+    int rc = gpmi_approx_Lz(ctx(), Rf_asReal(l), REAL(z), REAL(f));
+    UNPROTECT(1);
+    check(rc);
+    return f;
 }
 
 /* c(logml, sum log L_ii, z'z): one evaluation of models/fit_hyperparameters.stan:18-32 */

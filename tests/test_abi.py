@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "gpmi.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpmi_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(gpmi_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_build_and_exports():
@@ -21,7 +21,7 @@ def test_build_and_exports():
     lib = _build.build()
     assert os.path.exists(lib)
     out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
-    exported = set(re.findall(r" T (gpmi_[a-z0-9_]+)", out))
+    exported = set(re.findall(r" T (gpmi_[A-Za-z0-9_]+)", out))
     declared = _header_functions()
     assert declared, "header parse found nothing"
     missing = [f for f in declared if f not in exported]

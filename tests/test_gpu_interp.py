@@ -1,0 +1,86 @@
+"""GPU: Cholesky-factor interpolation over the length-scale -- approx_L (covariance.cpp:49-96),
+approx_Lz (models/cubic_interpolated_gp.hpp:38-73) and the table build of test_interpolate.R:9-19."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(orc, x, lp):
+    Ls, dLs = zip(*[orc.rbf_cov_chol(x, l) for l in lp])
+    return list(Ls), list(dLs)
+
+
+def test_blend_of_a_loaded_table_is_the_oracles(ctx, orc):
+    x = np.linspace(0, 5, 40); lp = np.array([0.5, 0.7, 0.9, 1.2])
+    Ls, dLs = _table(orc, x, lp)
+    ctx.interp_load(lp, Ls, dLs)
+    z = np.sin(0.3 * np.arange(40.0))
+    for l in (0.5, 0.55, 0.7, 0.81, 1.19, 1.2):
+        got = ctx.approx_L(l)
+        want = orc.approx_L(l, lp, Ls, dLs)
+        assert np.max(np.abs(got - want)) <= 4e-16 * np.max(np.abs(want)), l  # same formula, same operation order
+        assert np.all(np.triu(got, 1) == 0.0)
+        np.testing.assert_allclose(ctx.approx_Lz(l, z), orc.approx_Lz(l, lp, Ls, dLs, z), rtol=1e-13, atol=1e-14)
+    # outside the table the last / first interval is extrapolated (the reference reads past the end there)
+    for l in (0.3, 1.5):
+        np.testing.assert_allclose(ctx.approx_L(l), orc.approx_L(l, lp, Ls, dLs), rtol=1e-14, atol=1e-15)
+    ctx.interp_free()
+
+
+def test_table_built_on_the_device(ctx, orc):
+    # gpmi_interp_build == P calls of rbf_cov_chol (test_interpolate.R:9-19).  With the reference's
+    # 1e-10 jitter the factor of a densely sampled kernel is defined only to ~cond * eps, so the grid
+    # here is sparse enough (cond ~ 1e4) for two fp64 factorisations to agree to 1e-10
+    x = np.linspace(0, 8, 12); lp = np.linspace(0.6, 1.1, 5)
+    ctx.interp_build(x, lp)
+    Ls, dLs = _table(orc, x, lp)
+    for l in (0.6, 0.72, 1.03):
+        got = ctx.approx_L(l)
+        want = orc.approx_L(l, lp, Ls, dLs)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    # at a knot the blend is the knot's own factor
+    Lk, _ = ctx.rbf_cov_chol(x, lp[2])
+    np.testing.assert_allclose(ctx.approx_L(lp[2]), Lk, rtol=0, atol=1e-12)
+    ctx.interp_free()
+
+
+def test_many_chunks_and_row_blocks(ctx, orc):
+    # indexing at a size with several 256-row blocks and 128-column chunks, ragged edges included;
+    # the table need not hold Cholesky factors for that
+    rng = np.random.default_rng(5)
+    n = 1111
+    lp = np.array([1.0, 2.0, 2.5])
+    Ls = [np.tril(rng.standard_normal((n, n))) for _ in lp]
+    dLs = [np.tril(rng.standard_normal((n, n))) for _ in lp]
+    ctx.interp_load(lp, Ls, dLs)
+    z = rng.standard_normal(n)
+    for l in (1.3, 2.2):
+        want_L = orc.approx_L(l, lp, Ls, dLs)
+        got_L = ctx.approx_L(l)
+        assert np.max(np.abs(got_L - want_L)) <= 1e-15 * np.max(np.abs(want_L))
+        got = ctx.approx_Lz(l, z)
+        np.testing.assert_allclose(got, want_L @ z, rtol=0, atol=1e-12 * np.abs(want_L).sum(axis=1).max())
+        assert np.array_equal(got, ctx.approx_Lz(l, z))  # fixed summation order: run-to-run identical
+    ctx.interp_free()
+
+
+def test_host_mirror_and_errors(ctx, orc):
+    import gp_amd
+    from gp_amd.covariance import approx_L, approx_Lz, FactorInterpolator
+    x = np.linspace(0, 2, 12); lp = [0.5, 0.8, 1.3]
+    Ls, dLs = _table(orc, x, lp)
+    z = np.arange(12.0)
+    np.testing.assert_allclose(approx_L(0.9, lp, Ls, dLs, ctx=ctx), orc.approx_L(0.9, lp, Ls, dLs), rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(approx_Lz(0.9, lp, Ls, dLs, z, ctx=ctx), orc.approx_Lz(0.9, lp, Ls, dLs, z), rtol=1e-13)
+    fi = FactorInterpolator(x, lp, ctx=ctx)
+    assert fi.L(0.7).shape == (12, 12) and fi.Lz(0.7, z).shape == (12,)
+    ctx.interp_free()
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.approx_L(0.7)  # no table
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.interp_load([0.5], Ls[:1], dLs[:1])  # one knot is no interval
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.interp_load([0.8, 0.5], Ls[:2], dLs[:2])  # not increasing
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.interp_build(x, [0.5, -1.0 + 0.5, 0.9])  # not increasing / non-positive

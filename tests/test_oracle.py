@@ -167,3 +167,12 @@ def test_synth_is_deterministic(orc):
     X, y = orc.synth(50, 3); X2, y2 = orc.synth(50, 3)
     assert np.array_equal(X, X2) and np.array_equal(y, y2)
     assert X.min() >= 0 and X.max() < 1 and abs(np.mean(X) - 0.5) < 0.1
+
+
+def test_approx_Lz_is_blend_times_z(orc):
+    # models/cubic_interpolated_gp.hpp:38-73: f = v z with v the approx_L blend
+    x = np.linspace(0, 3, 7); lp = np.array([0.4, 0.6, 1.0])
+    Ls, dLs = zip(*[orc.rbf_cov_chol(x, l) for l in lp])
+    z = np.cos(np.arange(7.0))
+    for l in (0.45, 0.6, 0.93):
+        np.testing.assert_allclose(orc.approx_Lz(l, lp, Ls, dLs, z), orc.approx_L(l, lp, Ls, dLs) @ z, rtol=1e-14, atol=1e-15)
