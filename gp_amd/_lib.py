@@ -23,7 +23,7 @@ SYMBOLS = (
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev",
-    "gpmi_interp_free",
+    "gpmi_interp_free", "gpmi_logml_grad",
     "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
 )
 
@@ -248,6 +248,17 @@ class Context:
         L = np.empty((n, n), order="F"); dL = np.empty((n, n), order="F")
         _chk(self._lib.gpmi_rbf_cov_chol(self._h, _p(x), n, _d(l), _p(L), max(n, 1), _p(dL), max(n, 1)))
         return L, dL
+
+    def logml_grad(self, X, y, alpha, ell, sigma, jitter=0.0):
+        """((logml, sum log L_ii, z'z), grad) with grad = (d/dalpha, d/dell..., d/dsigma)."""
+        X = _mat(X); y = _vec(y); ell = _vec(ell)
+        n, D = X.shape
+        if y.size != n:
+            raise GpmiError(-1, "X and y disagree on N")
+        out = np.empty(3); g = np.empty(2 + ell.size)
+        _chk(self._lib.gpmi_logml_grad(self._h, _p(X), n, max(n, 1), D, _p(y), _d(alpha), _p(ell), ell.size, _d(sigma),
+                                       _d(jitter), _p(out), _p(g)))
+        return out, g
 
     # ---- Cholesky-factor interpolation over the length-scale ------------------
     def interp_build(self, x, lp):

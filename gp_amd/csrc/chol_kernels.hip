@@ -1344,19 +1344,22 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
 }
 
 int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
-                      int mrows, const double *Fpack_all)
+                      int mrows, const double *Fpack_all, int upper_tri)
 {
+    // X <- X L^-T by block forward substitution over the 128-column panels.  upper_tri: X is
+    // upper triangular on entry (e.g. the identity) and stays so -- panel k then only has rows
+    // [0, k + kb), which cuts the work to a third.
     hipStream_t s = c->stream;
     const int NB = GPMI_NB;
     for (int k = 0; k < n; k += NB) {
         const int kb = (n - k < NB) ? n - k : NB;
         const double *Fp = Fpack_all + (size_t)(k / NB) * GPMI_FPACK;
-        hipLaunchKernelGGL(k_trsm_panel, dim3((mrows + 63) / 64), 256, 0, s, X + (size_t)k * ldx, ldx, 0,
-                           mrows, kb, Fp);
+        const int mr = (upper_tri && k + kb < mrows) ? k + kb : mrows;
+        hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)k * ldx, ldx, 0, mr, kb, Fp);
         const int r0 = k + kb;
         if (r0 < n)
             launch_gemm_nt(s, X + (size_t)k * ldx, ldx, L + (size_t)r0 + (size_t)k * ldl, ldl,
-                           X + (size_t)r0 * ldx, ldx, mrows, n - r0, kb, 1);
+                           X + (size_t)r0 * ldx, ldx, mr, n - r0, kb, 1);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "trsm launch failed: %s", hipGetErrorString(e));

@@ -1140,6 +1140,173 @@ extern "C" int gpmi_approx_Lz(gpmi_ctx *c, double l, const double *z, double *f)
     return 0;
 }
 
+// ---- gradient of the log marginal likelihood ---------------------------
+// d logml / d theta = 1/2 tr((a a' - K^-1) dK/dtheta), a = K^-1 y: what Stan's reverse-mode autodiff
+// hands NUTS for models/fit_hyperparameters.stan:18-32.  K^-1 = L^-T L^-1 is formed explicitly:
+// L^-T by a triangular-aware panel substitution from the identity (N^3/3 flop), then -K^-1 by the
+// same SYRK kernel as the factorisation's trailing update (N^3 flop) -- four Cholesky's worth of
+// MFMA work on top of the factorisation; the final contraction re-evaluates the kernel from the
+// inputs instead of reading K back.
+namespace {
+__global__ void k_set_identity(double *__restrict__ A, size_t ld, int n)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= n) return;
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j < n) A[(size_t)i + (size_t)j * ld] = (i == j) ? 1.0 : 0.0;
+    }
+}
+
+// a = U z for upper-triangular U (= L^-T): thread = row, columns j >= i
+__global__ __launch_bounds__(256) void k_upper_mv(const double *__restrict__ U, size_t ld, int n,
+                                                  const double *__restrict__ z, double *__restrict__ a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int j = i; j < n; ++j) acc += U[(size_t)i + (size_t)j * ld] * z[j];
+    a[i] = acc;
+}
+
+// per 64 x 64 tile of the lower triangle: sums of w g kse, w g kse (x_id - x_jd)^2 (d < D), [i == j] g
+// with g = (a_i a_j + Wij) / 2 (W holds -K^-1), w = 2 off the diagonal (symmetry), 1 on it
+constexpr int GRAD_NS = 2 + GPMI_MAXD;
+__global__ __launch_bounds__(256) void k_grad_partial(const double *__restrict__ X, int n, int ldx, SeParams p,
+                                                      const double *__restrict__ a, const double *__restrict__ W,
+                                                      size_t ld, double *__restrict__ part)
+{
+    __shared__ double red[256];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const int i = ti * 64 + (threadIdx.x & 63);
+    const int jbase = tj * 64 + (threadIdx.x >> 6) * 16;
+    double acc[GRAD_NS];
+#pragma unroll
+    for (int s = 0; s < GRAD_NS; ++s) acc[s] = 0.0;
+    if (i < n) {
+        double xi[GPMI_MAXD];
+#pragma unroll
+        for (int d = 0; d < GPMI_MAXD; ++d) xi[d] = d < p.D ? X[(size_t)i + (size_t)d * ldx] : 0.0;
+        const double ai = a[i];
+        for (int q = 0; q < 16; ++q) {
+            const int j = jbase + q;
+            if (j >= n || j > i) break;
+            double e = 0.0, r2[GPMI_MAXD];
+#pragma unroll
+            for (int d = 0; d < GPMI_MAXD; ++d) {
+                const double r = d < p.D ? xi[d] - X[(size_t)j + (size_t)d * ldx] : 0.0;
+                r2[d] = r * r;
+                e += r2[d] * p.inv_ell[d] * p.inv_ell[d];
+            }
+            const double kse = p.a2 * exp(-0.5 * e);
+            const double g = 0.5 * (ai * a[j] + W[(size_t)i + (size_t)j * ld]);
+            const double w = (i == j) ? 1.0 : 2.0;
+            acc[0] += w * g * kse;
+#pragma unroll
+            for (int d = 0; d < GPMI_MAXD; ++d) acc[1 + d] += w * g * kse * r2[d];
+            if (i == j) acc[1 + GPMI_MAXD] += g;
+        }
+    }
+    const size_t slot = ((size_t)ti * (ti + 1) / 2 + tj) * GRAD_NS;
+    for (int s = 0; s < GRAD_NS; ++s) {  // fixed-shape tree per quantity: deterministic
+        red[threadIdx.x] = acc[s];
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[slot + s] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ part, size_t ntiles,
+                                                     double *__restrict__ sums)
+{
+    __shared__ double red[1024];
+    for (int s = 0; s < GRAD_NS; ++s) {
+        double acc = 0.0;
+        for (size_t t = threadIdx.x; t < ntiles; t += 1024) acc += part[t * GRAD_NS + s];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int h = 512; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[s] = red[0];
+        __syncthreads();
+    }
+}
+}  // namespace
+
+void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
+                       int ncu);
+
+extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
+                               double alpha, const double *ell, int n_ell, double sigma, double jitter,
+                               double *out3, double *grad)
+{
+    ENTER(c);
+    if (n <= 0 || !X || !y || !out3 || !grad || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
+    if (D > GPMI_MAXD) return gpmi_fail(GPMI_EARG, "gradient supports D <= %d", GPMI_MAXD);
+    SeParams p;
+    int rc;
+    if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
+    double *dX, *dy;
+    if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
+    const int M = n + 1;
+    if ((rc = reserve_ws(c, M, n))) return rc;
+    const size_t ld = (size_t)c->ld;
+    const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
+    double *U, *vec, *Fall;
+    if ((rc = stage_buf(c, 2, ldu * (size_t)(n + 1) * sizeof(double), &U))) return rc;
+    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS + ntiles * GRAD_NS) * sizeof(double), &vec))) return rc;
+    if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
+    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS;
+    hipStream_t s = c->stream;
+    // factorisation with the augmented row, all panel factors kept
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    launch_se_cov(s, dX, n, n, nullptr, n, n, p, sigma * sigma + jitter, 1, c->W, ld);
+    launch_set_row(s, c->W, ld, n, dy, n, n);
+    if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, Fall))) return rc;
+    launch_logml_finalize(s, c->W, ld, n, n, c->d_info, c->d_out, c->d_info + 1);
+    launch_get_row(s, c->W, ld, n, 0, n, 1.0, zv);
+    // U = L^-T, a = U z = K^-1 y
+    hipLaunchKernelGGL(k_set_identity, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, ldu, n);
+    if ((rc = launch_trsm_right(c, c->W, ld, n, U, ldu, n, Fall, 1))) return rc;
+    hipLaunchKernelGGL(k_upper_mv, dim3((n + 255) / 256), 256, 0, s, U, ldu, n, zv, av);
+    // W(lower) = -U U^T = -K^-1
+    HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
+    launch_syrk_probe(s, U, ldu, c->W, ld, n, n, c->d_ctr, c->ncu);
+    hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, n, p, av, c->W, ld, part);
+    hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, sums);
+    HIPCHK(hipGetLastError());
+    double hs[GRAD_NS];
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(out3, c->d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&info, c->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hs, sums, sizeof(hs), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (info) {
+        for (int k = 0; k < 2 + n_ell; ++k) grad[k] = NAN;
+        return info;
+    }
+    grad[0] = 2.0 * hs[0] / alpha;
+    if (n_ell == 1) {
+        double t = 0.0;
+        for (int d = 0; d < D; ++d) t += hs[1 + d];
+        grad[1] = t / (ell[0] * ell[0] * ell[0]);
+    } else {
+        for (int d = 0; d < D; ++d) grad[1 + d] = hs[1 + d] / (ell[d] * ell[d] * ell[d]);
+    }
+    grad[1 + n_ell] = 2.0 * sigma * hs[1 + GPMI_MAXD];
+    return 0;
+}
+
 // ---- GP posterior ---------------------------------------------------------------
 extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const double *ts, int m,
                                  const double *y, double alpha, double l, double s2, double jitter,

@@ -35,6 +35,19 @@ def fit_hyperparameters_log_prob(t, y, rho, alpha, sigma, ctx=None):
     return stan_lp(sld, q, alpha, rho, sigma)
 
 
+def fit_hyperparameters_log_prob_grad(t, y, rho, alpha, sigma, ctx=None):
+    """(lp__, d lp__/d(rho, alpha, sigma)) on the constrained scale -- the value/gradient pair Stan's
+    autodiff produces per leapfrog step for fit_hyperparameters.stan; feeds an optimiser or HMC outside
+    Stan.  Prior and Jacobian terms of stan_lp() differentiate to 4/rho - 4, 1/alpha - alpha,
+    1/sigma - sigma."""
+    try:
+        out, g = (ctx or default_context()).logml_grad(t, y, alpha, [rho], sigma, 0.0)
+    except NotPositiveDefinite:
+        return -math.inf, np.full(3, math.nan)
+    lp = stan_lp(out[1], out[2], alpha, rho, sigma)
+    return lp, np.array([g[1] + 4.0 / rho - 4.0, g[0] + 1.0 / alpha - alpha, g[2] + 1.0 / sigma - sigma])
+
+
 def gp_log_marginal_grid(X, y, alpha, rho_vec, sigma_vec, jitter=0.0, lp=False, ctx=None):
     """|rho| x |sigma| matrix of log marginal likelihoods (lp=True: Stan lp__ instead);
     non-PD points are NaN (-inf for lp) and the grid continues."""

@@ -136,6 +136,15 @@ int gpmi_logml_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const
                    double alpha, const double *ell, int n_ell, double sigma, double jitter,
                    double *d_out3, int *d_info);
 
+/* Log marginal likelihood AND its gradient with respect to (alpha, ell[0..n_ell), sigma):
+ * grad[0] = d/dalpha, grad[1 .. n_ell] = d/dell, grad[1 + n_ell] = d/dsigma.  This is what Stan's
+ * autodiff computes per leapfrog step for models/fit_hyperparameters.stan:18-32 (the reference has
+ * no function of its own for it); 1/2 tr((a a' - K^-1) dK/dtheta) with K^-1 formed on the device.
+ * D <= 8.  Same status codes as gpmi_logml (k > 0: not positive definite, grad = NaN). */
+int gpmi_logml_grad(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+                    double alpha, const double *ell, int n_ell, double sigma, double jitter,
+                    double *out3, double *grad);
+
 /* G independent hyper-parameter points (alpha[g], rho[g], sigma[g]) on the same
  * data: out3[3*g..], info[g].  Non-PD points get NaN and info[g] = k and the
  * grid continues.  Replaces the stan()-fit + arg-max of R/tests.R:13-27 when a

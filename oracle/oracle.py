@@ -150,6 +150,15 @@ def logml(X, y, alpha, rho, sigma, jitter=0.0):
     return out[0], out[1], out[2], info
 
 
+def logml_grad(X, y, alpha, rho, sigma, jitter=0.0):
+    """((logml, sum log L_ii, z'z), (d/dalpha, d/drho, d/dsigma), info)."""
+    X = _f(np.asarray(X, dtype=np.float64).reshape(len(y), -1)); n, D = X.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.empty(3); g = np.empty(3)
+    info = lib().orc_logml_grad(_p(X), n, n, D, _p(y), _d(alpha), _d(rho), _d(sigma), _d(jitter), _p(out), _p(g))
+    return out, g, info
+
+
 def stan_lp(sum_log_diag, quad, alpha, rho, sigma):
     return lib().orc_stan_lp(sum_log_diag, quad, alpha, rho, sigma)
 

@@ -60,6 +60,10 @@ gp_interp_Lz <- function(l, z) .Call("gpmi_R_approx_Lz", l, numeric(0), NULL, NU
 gp_log_marginal <- function(X, y, alpha, rho, sigma, jitter = 0)
   .Call("gpmi_R_logml", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)[1]
 
+# value and gradient w.r.t. (alpha, rho, sigma): feeds optim(..., method = "L-BFGS-B") in place of a Stan fit
+gp_log_marginal_grad <- function(X, y, alpha, rho, sigma, jitter = 0)
+  .Call("gpmi_R_logml_grad", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)
+
 gp_log_marginal_grid <- function(X, y, alpha, rho_vec, sigma_vec, jitter = 0) {
   g <- expand.grid(rho = rho_vec, sigma = sigma_vec)
   r <- .Call("gpmi_R_logml_grid", as.matrix(X), as.double(y), rep(alpha, nrow(g)), g$rho, g$sigma, jitter)

@@ -159,6 +159,23 @@ SEXP gpmi_R_logml(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)
     return out;
 }
 
+/* list(value = c(logml, sum log L_ii, z'z), grad = c(d/dalpha, d/dell..., d/dsigma)): what Stan's
+ * autodiff computes per leapfrog step for models/fit_hyperparameters.stan:18-32 */
+SEXP gpmi_R_logml_grad(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X), ne = Rf_length(ell);
+    SEXP val = PROTECT(Rf_allocVector(REALSXP, 3)), g = PROTECT(Rf_allocVector(REALSXP, 2 + ne));
+    int rc = gpmi_logml_grad(ctx(), REAL(X), n, n, D, REAL(y), Rf_asReal(alpha), REAL(ell), ne,
+                             Rf_asReal(sigma), Rf_asReal(jitter), REAL(val), REAL(g));
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2)), names = PROTECT(Rf_allocVector(STRSXP, 2));
+    SET_VECTOR_ELT(out, 0, val); SET_VECTOR_ELT(out, 1, g);
+    SET_STRING_ELT(names, 0, Rf_mkChar("value")); SET_STRING_ELT(names, 1, Rf_mkChar("grad"));
+    Rf_setAttrib(out, R_NamesSymbol, names);
+    UNPROTECT(4);
+    check(rc);
+    return out;
+}
+
 /* G x 3 matrix + info for a hyper-parameter grid (non-PD points NaN, grid continues) */
 SEXP gpmi_R_logml_grid(SEXP X, SEXP y, SEXP alpha, SEXP rho, SEXP sigma, SEXP jitter)
 {

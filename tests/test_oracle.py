@@ -176,3 +176,18 @@ def test_approx_Lz_is_blend_times_z(orc):
     z = np.cos(np.arange(7.0))
     for l in (0.45, 0.6, 0.93):
         np.testing.assert_allclose(orc.approx_Lz(l, lp, Ls, dLs, z), orc.approx_L(l, lp, Ls, dLs) @ z, rtol=1e-14, atol=1e-15)
+
+
+def test_logml_grad_matches_finite_differences(orc):
+    # no reference fixture exists for the gradient (Stan computes it by autodiff): the restated formula
+    # 1/2 tr((aa' - K^-1) dK) is pinned by central differences of the (KAT-pinned) log marginal likelihood
+    rng = np.random.default_rng(11)
+    X = rng.random((40, 2)); y = np.sin(3 * X[:, 0]) + 0.1 * rng.standard_normal(40)
+    a, r, s = 1.3, 0.45, 0.2
+    out, g, info = orc.logml_grad(X, y, a, r, s)
+    assert info == 0 and out[0] == pytest.approx(orc.logml(X, y, a, r, s)[0], rel=1e-13)
+    h = 1e-5
+    fd = [(orc.logml(X, y, a + h, r, s)[0] - orc.logml(X, y, a - h, r, s)[0]) / (2 * h),
+          (orc.logml(X, y, a, r + h, s)[0] - orc.logml(X, y, a, r - h, s)[0]) / (2 * h),
+          (orc.logml(X, y, a, r, s + h)[0] - orc.logml(X, y, a, r, s - h)[0]) / (2 * h)]
+    np.testing.assert_allclose(g, fd, rtol=2e-7)
