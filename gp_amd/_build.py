@@ -23,6 +23,7 @@ def needs_build():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [
         os.path.join(CSRC, "gpmi_internal.h"),
+        os.path.join(CSRC, "factor16.h"),
         os.path.join(HERE, "..", "include", "gpmi.h"),
     ]
     return any(os.path.getmtime(d) > t for d in deps)

@@ -25,9 +25,12 @@ __device__ __forceinline__ double bcast16(double v)
 
 // Cholesky of a 16x16 SPD tile held in LDS as [row][col] (lower triangle used) and the
 // inverse of its factor.  One wave; every lane keeps matrix row lane&15 in registers (the four
-// 16-lane DPP rows hold identical copies), pivots and multipliers travel by DPP row
-// broadcast, so everything stays in VGPRs.  Out: s_d16 = L16 (upper zeroed), s_inv = L16^-1
-// in MFMA A-operand order s_inv[kg*64 + l] = Linv[l&15][(l>>4) + 4*kg].  Returns 0 or
+// 16-lane DPP rows hold identical copies of the factor), pivots and multipliers travel by DPP
+// row broadcast, so everything stays in VGPRs.  The inverse Y = L16^-1 is split over the DPP
+// rows by columns -- lane (r, q) carries Y[r][q + 4 i], i = 0..3, which is exactly the MFMA
+// A-operand order it is published in -- and its step k (needs only column k of L and 1/L_kk)
+// is issued right behind pivot k, in the shadow of the pivot chain's latencies.
+// Out: s_d16 = L16 (upper zeroed), s_inv[kg*64 + l] = Linv[l&15][(l>>4) + 4*kg].  Returns 0 or
 // 1 + index of the first non-positive pivot.
 __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int lane)
 {
@@ -35,19 +38,26 @@ __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int 
     double row[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] = s_d16[lr][c];
-    int bad = 0;
-    double dinv[16];  // 1 / L_jj (wave-uniform values)
     double own_dinv = 1.0;  // 1 / L_rr of this lane's own row
+    double acc[4];          // Y[r][lq + 4 i] before the final scaling by 1 / L_rr
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (lq + 4 * i == lr) ? 1.0 : 0.0;
     static_for<0, 16>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        double d = bcast16<j>(row[j]);
-        const bool neg = !(d > 0.0);
-        bad = (neg && !bad) ? j + 1 : bad;
-        d = neg ? 1.0 : d;
-        // The 128-pivot chain is the critical path of the whole panel phase: the multipliers
-        // use 1/sqrt(d) straight from rsqrt (<= 1 ulp); the diagonal entry and its reciprocal
-        // (needed only by the inverse, later) get a Newton correction off the chain.
-        const double ri = rsqrt(d);
+        // lane masks are recomputed per pivot from an opaque copy of the row index: kept live
+        // for all 16 pivots they overflow the SGPR file and get spilled to VGPR lanes
+        int lrj = lr;
+        asm volatile("" : "+v"(lrj));
+        const double d = bcast16<j>(row[j]);
+        // The 128-pivot chain is the critical path of the whole panel phase.  No pivot test sits
+        // on it: a non-positive (or NaN) pivot turns 1/L_jj into NaN or a negative number and
+        // is found from that after the loop.  rsqrt = v_rsq_f64 (~2^-26) + one cubic step
+        // (<= 1 ulp), without the library's zero / infinity special cases; the multipliers use
+        // it as it is, the diagonal entry and its reciprocal (needed only by the inverse) get a
+        // Newton correction off the chain.
+        const double y0 = __builtin_amdgcn_rsq(d);
+        const double e = fma(-(y0 * d), y0, 1.0);
+        const double ri = fma(y0 * e, fma(e, 0.375, 0.5), y0);
         const double cj = row[j] * ri;
         static_for<j + 1, 16>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -55,33 +65,28 @@ __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int 
         });
         double s = d * ri;
         s = fma(0.5 * ri, fma(-s, s, d), s);
-        dinv[j] = fma(ri, fma(-s, ri, 1.0), ri);
-        own_dinv = (lr == j) ? dinv[j] : own_dinv;
-        row[j] = (lr == j) ? s : cj;
-    });
-    // Inverse by rows: Y = L16^-1, lane r accumulates row r.  At step k row k is final
-    // (acc_k * 1/L_kk), is broadcast from lane k, and every lane r > k subtracts L[r][k] * Y[k][:].
-    // Each broadcast depends on a value computed in the previous step, so hipcc cannot hoist
-    // them all up front (the column-oriented form cost > 256 VGPRs that way).
-    double acc[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = (c == lr) ? 1.0 : 0.0;
-    static_for<0, 16>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        const double m = (lr > k) ? row[k] : 0.0;  // L[r][k] for the rows still open
-        static_for<0, k + 1>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            const double y = bcast16<k>(acc[c]) * dinv[k];  // Y[k][c]
-            acc[c] = fma(-m, y, acc[c]);
+        const double dinv = fma(ri, fma(-s, ri, 1.0), ri);
+        own_dinv = (lrj == j) ? dinv : own_dinv;
+        row[j] = (lrj == j) ? s : cj;
+        // Inverse, step j: row j of Y is final (acc_j / L_jj), is broadcast from lane j of each
+        // DPP row, and every lane r > j subtracts L[r][j] * Y[j][:].  Columns past j are still
+        // zero in lane j, so the registers i > j/4 need no work.
+        const double m = (lrj > j) ? cj : 0.0;
+        static_for<0, j / 4 + 1>([&](auto ic_) {
+            constexpr int i = decltype(ic_)::value;
+            const double y = bcast16<j>(acc[i]) * dinv;
+            acc[i] = fma(-m, y, acc[i]);
         });
     });
+    // first row whose pivot was not a positive finite number (lanes 0..15 hold rows 0..15)
+    const unsigned long long badmask = __ballot(!(own_dinv > 0.0) || !(own_dinv < INFINITY)) & 0xffffull;
+    const int bad = badmask ? __builtin_ctzll(badmask) + 1 : 0;
     if (lq == 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) s_d16[lr][c] = (c <= lr) ? row[c] : 0.0;
-        // A-operand order: s_inv[kg*64 + l] = Linv[j = l&15][k = (l>>4) + 4*kg]; lane j = lr holds row j
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s_inv[(k >> 2) * 64 + lr + 16 * (k & 3)] = (k <= lr) ? acc[k] * own_dinv : 0.0;
     }
-    // all lanes saw the same pivots; make the flag wave-uniform for the caller
-    return __builtin_amdgcn_readfirstlane(bad);
+    // A-operand order: register i of lane (r, q) is Linv[r][q + 4 i] (zero above the diagonal)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_inv[i * 64 + lane] = acc[i] * own_dinv;
+    return bad;
 }
