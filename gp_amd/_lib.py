@@ -24,6 +24,7 @@ SYMBOLS = (
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev",
     "gpmi_interp_free", "gpmi_logml_grad",
+    "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
     "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
 )
 
@@ -308,6 +309,10 @@ class Context:
                                          max(m, 1)))
         return mn, Kn
 
+    def seq_sampler(self, X, mn, Kn, alpha, ell, jitter=1e-6, max_steps=256):
+        """Sequential conditional sampler (create_p_dotXnS, R/ode_gp_library.R:43-93)."""
+        return SeqSampler(self, X, mn, Kn, alpha, ell, jitter, max_steps)
+
     # ---- device-pointer API (torch tensors own the memory; plumbing only) -----
     def logml_dev(self, dX_ptr, n, ldx, D, dy_ptr, alpha, ell, sigma, jitter, dout_ptr, dinfo_ptr):
         ell = _vec(ell)
@@ -351,6 +356,49 @@ class Context:
         t = C.c_double(0.0); mhz = C.c_double(0.0)
         _chk(self._lib.gpmi_probe_mfma_peak(self._h, int(iters), C.byref(t), C.byref(mhz)))
         return t.value, mhz.value
+
+
+class SeqSampler:
+    """One gpmi_seq: step(xs) -> (condMean, condVar) of the new point given the committed draws,
+    commit(dot_xs) appends the draw."""
+
+    def __init__(self, ctx, X, mn, Kn, alpha, ell, jitter=1e-6, max_steps=256):
+        X = _mat(X); mn = _vec(mn); Kn = _mat(Kn); ell = _vec(ell)
+        n, D = X.shape
+        if mn.size != n or Kn.shape != (n, n):
+            raise GpmiError(-1, "X, mn and Kn disagree on N")
+        self._ctx = ctx  # keeps the context alive
+        self._lib = ctx._lib
+        self._h = C.c_void_p()
+        self.D = D
+        _chk(self._lib.gpmi_seq_create(ctx._h, C.byref(self._h), _p(X), n, max(n, 1), D, _p(mn), _p(Kn), max(n, 1),
+                                       _d(alpha), _p(ell), int(ell.size), _d(jitter), int(max_steps)))
+
+    def step(self, xs):
+        xs = _vec(xs)
+        if xs.size != self.D:
+            raise GpmiError(-1, "xs must have D = %d entries" % self.D)
+        out = np.empty(2)
+        _chk(self._lib.gpmi_seq_step(self._h, _p(xs), _p(out)))
+        return out[0], out[1]
+
+    def commit(self, dot_xs):
+        _chk(self._lib.gpmi_seq_commit(self._h, _d(dot_xs)))
+
+    @property
+    def count(self):
+        return self._lib.gpmi_seq_count(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gpmi_seq_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _default = {}

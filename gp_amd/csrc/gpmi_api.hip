@@ -1356,6 +1356,345 @@ extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const doub
     return info;
 }
 
+// ---- sequential conditional sampler -------------------------------------
+// create_p_dotXnS, R/ode_gp_library.R:43-93.  The reference re-derives, at every call, the joint
+// mean and covariance of ALL star points so far,
+//   m = K_XsX K~^-1 mn,   K = K_XsXs - K_XsX K~^-1 K_XXs + K_XsX K~^-1 Kn K~^-1 K_XXs   (:74-76)
+// (K~ = K_XX + 1e-6 I through a QR factorisation, :55-57), symmetrises it, adds 1e-6 I (:77) and
+// conditions the newest point on the draws already made with condMVN (:80-81): O(i N^2 + i^3) per
+// call.  Here everything is expressed through the Cholesky factor K~ = L L^T and whitened kernel
+// rows t_i = L^-1 k(X, xs_i) (norm <= alpha: no cancellation of 1/jitter-sized numbers, unlike an
+// explicit K~^-1, which loses cond(K~) * eps * |K~^-1| -- 1e-5 in the R/tests.R:78 scenario):
+//   once, on the device:  B = I - sym(L^-1 Kn L^-T)  (two N-row panel solves),  b = L^-1 mn;
+//   per call:  t_i (one one-row panel solve, reads the factor once), u = B t_i (HBM-bound
+//   mat-vec), K[i,j] = k(xs_i, xs_j) - t_j . u,  m_i = t_i . b  (i + 2 dot products), and one row
+//   appended to the Cholesky factor of the star covariance: with K[g,g] = Ls Ls^T and
+//   l = Ls^-1 K[g,i],  condMean = m_i + l . w,  condVar = K[i,i] - l . l,  w = Ls^-1 (dots - m_g)
+//   -- the same numbers as condMVN's solve, without re-factoring.
+struct gpmi_seq {
+    gpmi_ctx *c;
+    int n, D, max_steps, i, pending;
+    SeParams p;
+    double jitter;
+    size_t ldm;
+    double *dX, *L, *Fall, *B, *a, *Kx, *Xs, *Ls, *u, *part, *ks, *w, *res, *kcol, *row2;
+    int nchunk;
+};
+
+namespace {
+constexpr int MV_ROWS = 256, MV_COLS = 512;
+
+// B = I - (G + Gt) / 2 from G and its transposed copy (both read along columns)
+__global__ __launch_bounds__(256) void k_seq_b(const double *__restrict__ G, const double *__restrict__ Gt, size_t ld,
+                                               double *__restrict__ Bm, int n)
+{
+    const int r = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (r >= n) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q;
+        if (c < n) {
+            const size_t o = (size_t)r + (size_t)c * ld;
+            Bm[o] = (r == c ? 1.0 : 0.0) - 0.5 * (G[o] + Gt[o]);
+        }
+    }
+}
+
+// part[chunk][row] = sum over the chunk's columns of A[row, col] x[col]; thread = row (a wave
+// reads 512 contiguous bytes of each column), four accumulators in a fixed order
+__global__ __launch_bounds__(MV_ROWS) void k_mv_part(const double *__restrict__ A, size_t lda, int n,
+                                                     const double *__restrict__ x, double *__restrict__ part)
+{
+    const int r = blockIdx.x * MV_ROWS + threadIdx.x;
+    const int c0 = blockIdx.y * MV_COLS;
+    const int c1 = (c0 + MV_COLS < n) ? c0 + MV_COLS : n;
+    if (r >= n) return;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const double *col = A + (size_t)r + (size_t)c0 * lda;
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fma(col[(size_t)q * lda], x[c + q], acc[q]);
+        col += 4 * lda;
+    }
+    for (; c < c1; ++c) {
+        acc[0] = fma(col[0], x[c], acc[0]);
+        col += lda;
+    }
+    part[(size_t)blockIdx.y * n + r] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__global__ __launch_bounds__(256) void k_mv_sum(const double *__restrict__ part, int n, int nchunk, double scale,
+                                                double *__restrict__ y)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double acc = 0.0;
+    for (int q = 0; q < nchunk; ++q) acc += part[(size_t)q * n + r];
+    y[r] = scale * acc;
+}
+
+// Kx holds the whitened rows t_j.  block j <= i: ks[j] = k(xs_i, xs_j) - t_j . u (+ jitter on
+// j == i); block i + 1: ks[max_steps] = t_i . a  (the prior mean of the new point).  Fixed-shape tree: deterministic.
+__global__ __launch_bounds__(256) void k_seq_dots(const double *__restrict__ Kx, int n, int i,
+                                                  const double *__restrict__ u, const double *__restrict__ a,
+                                                  const double *__restrict__ Xs, int max_steps, SeParams p,
+                                                  double jitter, double *__restrict__ ks)
+{
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    const double *col = Kx + (size_t)(j <= i ? j : i) * n;
+    const double *v = (j <= i) ? u : a;
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n; r += 256) acc = fma(col[r], v[r], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (j > i) {
+            ks[max_steps] = red[0];
+        } else {
+            double e = 0.0;
+            for (int d = 0; d < p.D; ++d) {
+                const double r = (Xs[(size_t)i + (size_t)d * max_steps] - Xs[(size_t)j + (size_t)d * max_steps]) * p.inv_ell[d];
+                e += r * r;
+            }
+            ks[j] = p.a2 * exp(-0.5 * e) - red[0] + (j == i ? jitter : 0.0);
+        }
+    }
+}
+
+// One workgroup: l = Ls^-1 ks[0:i) by column-oriented forward substitution in LDS, then
+// res = (condMean, condVar, sqrt(condVar)), row i of Ls.  info: 1 + i when condVar <= 0.
+__global__ __launch_bounds__(256) void k_seq_cond(double *__restrict__ Ls, int ldl, int i,
+                                                  const double *__restrict__ ks, int max_steps,
+                                                  const double *__restrict__ w, double *__restrict__ res,
+                                                  int *__restrict__ info)
+{
+    extern __shared__ double b[];
+    __shared__ double red[2][256];
+    for (int t = threadIdx.x; t < i; t += 256) b[t] = ks[t];
+    __syncthreads();
+    for (int j = 0; j < i; ++j) {
+        if (threadIdx.x == 0) b[j] /= Ls[(size_t)j + (size_t)j * ldl];
+        __syncthreads();
+        const double bj = b[j];
+        for (int t = j + 1 + threadIdx.x; t < i; t += 256) b[t] = fma(-Ls[(size_t)t + (size_t)j * ldl], bj, b[t]);
+        __syncthreads();
+    }
+    double ll = 0.0, lw = 0.0;
+    for (int t = threadIdx.x; t < i; t += 256) {
+        ll = fma(b[t], b[t], ll);
+        lw = fma(b[t], w[t], lw);
+        Ls[(size_t)i + (size_t)t * ldl] = b[t];
+    }
+    red[0][threadIdx.x] = ll;
+    red[1][threadIdx.x] = lw;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + h];
+            red[1][threadIdx.x] += red[1][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double var = ks[i] - red[0][0];
+        const double sd = sqrt(var);
+        res[0] = ks[max_steps] + red[1][0];
+        res[1] = var;
+        res[2] = sd;
+        Ls[(size_t)i + (size_t)i * ldl] = sd;
+        *info = (var > 0.0) ? 0 : i + 1;
+    }
+}
+
+__global__ void k_seq_commit(double *__restrict__ w, int i, double dot, const double *__restrict__ res)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) w[i] = (dot - res[0]) / res[2];
+}
+}  // namespace
+
+static void seq_mv(gpmi_seq *q, hipStream_t s, const double *A, size_t lda, const double *x, double scale, double *y)
+{
+    const int n = q->n;
+    hipLaunchKernelGGL(k_mv_part, dim3((n + MV_ROWS - 1) / MV_ROWS, q->nchunk), MV_ROWS, 0, s, A, lda, n, x, q->part);
+    hipLaunchKernelGGL(k_mv_sum, dim3((n + 255) / 256), 256, 0, s, q->part, n, q->nchunk, scale, y);
+}
+
+extern "C" int gpmi_seq_destroy(gpmi_seq *q)
+{
+    if (!q) return 0;
+    gpmi_ctx *c = q->c;
+    if (c && c->pid == (int)getpid()) {
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+        hipFree(q->dX);
+        hipFree(q->L);
+        hipFree(q->Fall);
+        hipFree(q->B);
+        hipFree(q->Kx);
+        hipFree(q->Ls);
+        hipFree(q->u);
+    }
+    free(q);
+    return 0;
+}
+
+extern "C" int gpmi_seq_create(gpmi_ctx *c, gpmi_seq **out, const double *X, int n, int ldx, int D,
+                               const double *mn, const double *Kn, int ldkn, double alpha, const double *ell,
+                               int n_ell, double jitter, int max_steps)
+{
+    ENTER(c);
+    if (!out) return gpmi_fail(GPMI_EARG, "out pointer is NULL");
+    *out = nullptr;
+    if (n <= 0 || !X || !mn || !Kn || ldx < n || ldkn < n) return gpmi_fail(GPMI_EARG, "bad argument");
+    if (max_steps < 1 || max_steps > 2048) return gpmi_fail(GPMI_EARG, "max_steps must be in 1..2048");
+    SeParams p;
+    int rc;
+    if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
+    gpmi_seq *q = (gpmi_seq *)calloc(1, sizeof(gpmi_seq));
+    if (!q) return gpmi_fail(GPMI_ENOMEM, "host allocation failed");
+    q->c = c;
+    q->n = n;
+    q->D = D;
+    q->max_steps = max_steps;
+    q->p = p;
+    q->jitter = jitter;
+    q->ldm = (size_t)(((n + 15) / 16) * 16 + 16);
+    q->nchunk = (n + MV_COLS - 1) / MV_COLS;
+    const size_t ldm = q->ldm, ms = (size_t)max_steps;
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    const size_t nvec = 3 * (size_t)n + (size_t)q->nchunk * n + 2 * ms + 32 + 2 * ((size_t)n + 1) + 4096;
+#define SEQ_ALLOC(ptr, count)                                                                      \
+    if (hipMalloc((void **)&(ptr), (count) * sizeof(double)) != hipSuccess) {                      \
+        gpmi_seq_destroy(q);                                                                       \
+        return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes for the sampler", (size_t)(count) * sizeof(double)); \
+    }
+    SEQ_ALLOC(q->dX, (size_t)n * D + ms * D)
+    SEQ_ALLOC(q->L, ldm * (size_t)(n + 1) + 4096)
+    SEQ_ALLOC(q->Fall, (size_t)npan * GPMI_FPACK)
+    SEQ_ALLOC(q->B, ldm * (size_t)(n + 1) + 4096)
+    SEQ_ALLOC(q->Kx, (size_t)n * ms)
+    SEQ_ALLOC(q->Ls, ms * ms)
+    SEQ_ALLOC(q->u, nvec)
+#undef SEQ_ALLOC
+    q->Xs = q->dX + (size_t)n * D;
+    q->a = q->u + n;
+    q->kcol = q->a + n;
+    q->part = q->kcol + n;
+    q->ks = q->part + (size_t)q->nchunk * n;
+    q->w = q->ks + ms + 1;
+    q->res = q->w + ms;
+    q->row2 = q->res + 16;  // 1 x n row vector with ld = 2, followed by the tile over-read slack
+#define SEQ_TRY(expr)            \
+    if ((rc = (expr))) {         \
+        gpmi_seq_destroy(q);     \
+        return rc;               \
+    }
+    hipStream_t s = c->stream;
+    SEQ_TRY(reserve_ws(c, n, n))
+    const size_t ld = (size_t)c->ld;
+    double *dKn, *U;
+    SEQ_TRY(stage_buf(c, 0, ldm * (size_t)(n + 1) * sizeof(double), &dKn))
+    SEQ_TRY(stage_buf(c, 2, ldm * (size_t)(n + 1) * sizeof(double), &U))
+    auto fail_hip = [&](hipError_t e, const char *what) {
+        gpmi_seq_destroy(q);
+        return gpmi_fail(GPMI_EHIP, "%s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMemcpy2DAsync(q->dX, (size_t)n * sizeof(double), X, (size_t)ldx * sizeof(double),
+                              (size_t)n * sizeof(double), D, hipMemcpyHostToDevice, s)) != hipSuccess)
+        return fail_hip(e, "upload of X");
+    if ((e = hipMemcpy2DAsync(dKn, ldm * sizeof(double), Kn, (size_t)ldkn * sizeof(double), (size_t)n * sizeof(double),
+                              n, hipMemcpyHostToDevice, s)) != hipSuccess)
+        return fail_hip(e, "upload of Kn");
+    if ((e = hipMemcpyAsync(q->u, mn, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s)) != hipSuccess)
+        return fail_hip(e, "upload of mn");
+    if ((e = hipMemsetAsync(c->d_info, 0, sizeof(int), s)) != hipSuccess) return fail_hip(e, "memset");
+    if ((e = hipMemsetAsync(q->row2, 0, (2 * ((size_t)n + 1) + 4096) * sizeof(double), s)) != hipSuccess)
+        return fail_hip(e, "memset");
+    // K~ = K_XX + jitter I (:50,55), L = chol(K~) kept with its packed block factors
+    launch_se_cov(s, q->dX, n, n, nullptr, n, n, p, jitter, 1, c->W, ld);
+    SEQ_TRY(launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, q->Fall))
+    launch_copy_matrix(s, c->W, ld, q->L, ldm, n, n, 1);
+    // G^T = L^-1 Kn^T L^-T: (Kn L^-T), transposed, times L^-T again;  B = I - (G + G^T) / 2 (:76-77)
+    SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, dKn, ldm, n, q->Fall))
+    launch_transpose(s, dKn, ldm, U, ldm, n, n);
+    SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, U, ldm, n, q->Fall))
+    launch_transpose(s, U, ldm, dKn, ldm, n, n);
+    hipLaunchKernelGGL(k_seq_b, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, dKn, ldm, q->B, n);
+    // b = L^-1 mn (:56) as a one-row right-solve
+    launch_set_row(s, q->row2, 2, 0, q->u, n, n);
+    SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, q->row2, 2, 1, q->Fall))
+    launch_get_row(s, q->row2, 2, 0, 0, n, 1.0, q->a);
+    if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "sampler set-up launch");
+    int info = 0;
+    if ((e = hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess)
+        return fail_hip(e, "download");
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail_hip(e, "synchronise");
+#undef SEQ_TRY
+    if (info) {
+        gpmi_seq_destroy(q);
+        return info;
+    }
+    *out = q;
+    return 0;
+}
+
+extern "C" int gpmi_seq_step(gpmi_seq *q, const double *xs, double *out2)
+{
+    if (!q) return gpmi_fail(GPMI_EARG, "sampler is NULL");
+    gpmi_ctx *c = q->c;
+    ENTER(c);
+    if (!xs || !out2) return gpmi_fail(GPMI_EARG, "bad argument");
+    if (q->i >= q->max_steps) return gpmi_fail(GPMI_EARG, "sampler is full (max_steps = %d)", q->max_steps);
+    const int n = q->n, i = q->i, ms = q->max_steps;
+    hipStream_t s = c->stream;
+    // row i of Xs (leading dimension max_steps)
+    HIPCHK(hipMemcpy2DAsync(q->Xs + i, (size_t)ms * sizeof(double), xs, sizeof(double), sizeof(double), q->D,
+                            hipMemcpyHostToDevice, s));
+    double *ti = q->Kx + (size_t)i * n;
+    int rc;
+    launch_se_cov(s, q->dX, n, n, q->Xs + i, 1, ms, q->p, 0.0, 0, q->kcol, (size_t)n);  // K_XsX row (:71)
+    launch_set_row(s, q->row2, 2, 0, q->kcol, n, n);
+    if ((rc = launch_trsm_right(c, q->L, q->ldm, n, q->row2, 2, 1, q->Fall))) return rc;  // t_i = L^-1 k_i
+    launch_get_row(s, q->row2, 2, 0, 0, n, 1.0, ti);
+    seq_mv(q, s, q->B, q->ldm, ti, 1.0, q->u);
+    hipLaunchKernelGGL(k_seq_dots, dim3(i + 2), 256, 0, s, q->Kx, n, i, q->u, q->a, q->Xs, ms, q->p, q->jitter, q->ks);
+    hipLaunchKernelGGL(k_seq_cond, dim3(1), 256, (size_t)(i + 1) * sizeof(double), s, q->Ls, ms, i, q->ks, ms, q->w,
+                       q->res, c->d_info);
+    HIPCHK(hipGetLastError());
+    double res[3];
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(res, q->res, sizeof(res), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    out2[0] = res[0];
+    out2[1] = res[1];
+    q->pending = (info == 0);
+    return info;
+}
+
+extern "C" int gpmi_seq_commit(gpmi_seq *q, double dot_xs)
+{
+    if (!q) return gpmi_fail(GPMI_EARG, "sampler is NULL");
+    gpmi_ctx *c = q->c;
+    ENTER(c);
+    if (!q->pending) return gpmi_fail(GPMI_EARG, "gpmi_seq_commit without a preceding successful gpmi_seq_step");
+    hipLaunchKernelGGL(k_seq_commit, dim3(1), 64, 0, c->stream, q->w, q->i, dot_xs, q->res);
+    HIPCHK(hipGetLastError());
+    q->i += 1;
+    q->pending = 0;
+    return 0;
+}
+
+extern "C" int gpmi_seq_count(const gpmi_seq *q) { return q ? q->i : 0; }
+
 // ---- diagnostics ---------------------------------------------------------------
 extern "C" int gpmi_last_timing(gpmi_ctx *c, double *ms3)
 {

@@ -38,6 +38,7 @@ extern "C" {
 #define GPMI_VERSION 100
 
 typedef struct gpmi_ctx gpmi_ctx;
+typedef struct gpmi_seq gpmi_seq; /* sequential conditional sampler (gpmi_seq_*) */
 
 enum {
     GPMI_OK = 0,
@@ -203,6 +204,29 @@ int gpmi_interp_free(gpmi_ctx *ctx);
 int gpmi_gp_condition(gpmi_ctx *ctx, const double *t, int n, const double *ts, int m,
                       const double *y, double alpha, double l, double s2, double jitter,
                       int kindK, int kindS, int kindSS, int flags, double *mn, double *Kn, int ldkn);
+
+/* ---- sequential conditional sampler ------------------------------------ */
+
+/* create_p_dotXnS(Xn_list, mn, Kn, theta), R/ode_gp_library.R:43-93 (R/tests.R:78-91): a stateful
+ * sampler of the derivative at new states xs, one at a time, each conditioned on the draws
+ * already made.  X = do.call(cbind, Xn_list) (n x D), theta = (alpha, ell) of QQard; mn, Kn the
+ * derivative posterior at the data (p_dotXn); jitter = 1e-6 in the reference (:55 and :77).
+ * With K~ = K_XX + jitter I the joint law of the star points is N(m, K),
+ *   m = K_XsX K~^-1 mn,  K = K_XsXs - K_XsX (K~^-1 - K~^-1 Kn K~^-1) K_XXs + jitter I   (:74-77);
+ * gpmi_seq_step returns out2 = (condMean, condVar) of the NEW point given the committed draws
+ * (what condMVN returns at :80-81; the closure's `mu`, `sigma`), gpmi_seq_commit appends the
+ * value drawn for it (the reference draws rnorm(1, condMean, condVar) at :83 with R's RNG, so
+ * the draw itself belongs to the caller).  A step that is not committed is discarded by the next
+ * step.  The O(n^3) work (one Cholesky, two n-row triangular solves) happens once in
+ * gpmi_seq_create; a step reads 12 n^2 B (factor + one n x n matrix).  max_steps <= 2048.
+ * Status k > 0: K~ (create) or the star covariance (step, k = its order) is not positive definite. */
+int gpmi_seq_create(gpmi_ctx *ctx, gpmi_seq **out, const double *X, int n, int ldx, int D,
+                    const double *mn, const double *Kn, int ldkn, double alpha, const double *ell,
+                    int n_ell, double jitter, int max_steps);
+int gpmi_seq_step(gpmi_seq *seq, const double *xs /* D */, double *out2);
+int gpmi_seq_commit(gpmi_seq *seq, double dot_xs);
+int gpmi_seq_count(const gpmi_seq *seq); /* committed draws */
+int gpmi_seq_destroy(gpmi_seq *seq);
 
 /* ---- diagnostics (tests / bench) -------------------------------------- */
 

@@ -240,3 +240,66 @@ def synth(n, D, seed=20240601):
     X = np.empty((n, D), order="F"); y = np.empty(n)
     lib().orc_synth(n, D, C.c_ulonglong(seed), _p(X), _p(y))
     return X, y
+
+
+class create_p_dotXnS:
+    """create_p_dotXnS, R/ode_gp_library.R:43-93, restated statement by statement with numpy
+    (test infrastructure, like everything in this module).  The reference factors
+    K_XX + 1e-6 I with qr() and solves with it (:55-57, :76); every call rebuilds the joint mean
+    and covariance of all star points (:71-77) and conditions the newest on the earlier draws
+    with condMVNorm::condMVN (:80-81; third-party, unpinned: its published formula
+    cMu = mu_d + C D^-1 (x_g - mu_g), cVar = B - C D^-1 C' is restated in _condMVN).
+    rnorm's variate is supplied by the caller (z) -- R's RNG stream cannot be reproduced here;
+    compat_sd=True passes condVar as the standard deviation, as :83 is written.
+    Parity unpinned by the reference (no recorded outputs); pinned by
+    tests/test_oracle.py::test_seq_sampler_chain_equals_joint."""
+
+    def __init__(self, Xn_list, mn, Kn, alpha, ell, compat_sd=False):
+        self.X = np.column_stack([np.asarray(x, dtype=np.float64).ravel() for x in Xn_list])  # :45
+        self.N, self.D = self.X.shape
+        self.alpha, self.ell = float(alpha), np.atleast_1d(np.asarray(ell, dtype=np.float64))
+        self.i = 1
+        K_XX = QQard(self.X, self.X, self.alpha, self.ell)                                   # :50
+        self.K_XsX = np.zeros((0, self.N))
+        self.K_XsXs = np.zeros((0, 0))
+        self.Q, self.R = np.linalg.qr(K_XX + 1e-6 * np.eye(self.N))                          # :55
+        self.K_XX_1_mn = self._solve(np.asarray(mn, dtype=np.float64).reshape(-1, 1))       # :56
+        self.K_XX_1_Kn = self._solve(np.asarray(Kn, dtype=np.float64))                      # :57
+        self.Xs = np.zeros((0, self.D))
+        self.dot_Xs = np.zeros(0)
+        self.compat_sd = compat_sd
+
+    def _solve(self, B):
+        import scipy.linalg
+        return scipy.linalg.solve_triangular(self.R, self.Q.T @ B, lower=False)
+
+    @staticmethod
+    def _condMVN(mean, sigma, dep, given, x_given):
+        if len(given) == 0:
+            return mean[dep], sigma[np.ix_(dep, dep)]
+        B = sigma[np.ix_(dep, dep)]; Cm = sigma[np.ix_(dep, given)]; Dm = sigma[np.ix_(given, given)]
+        CDinv = Cm @ np.linalg.inv(Dm)   # condMVN: C %*% solve(D)
+        return mean[dep] + CDinv @ (x_given - mean[given]), B - CDinv @ Cm.T
+
+    def joint(self):
+        """(m, K) of all star points so far, :74-77."""
+        m = (self.K_XsX @ self.K_XX_1_mn).ravel()
+        S = self._solve(self.K_XsX.T)
+        K = self.K_XsXs - self.K_XsX @ S + self.K_XsX @ self.K_XX_1_Kn @ S
+        K = (K + K.T) / 2 + 1e-6 * np.eye(K.shape[0])
+        return m, K
+
+    def __call__(self, xs_vec, z):
+        xs = np.asarray(xs_vec, dtype=np.float64).reshape(1, -1)                             # :68
+        self.K_XsX = np.vstack([self.K_XsX, QQard(xs, self.X, self.alpha, self.ell)])       # :71
+        kq = QQard(self.Xs, xs, self.alpha, self.ell) if self.Xs.shape[0] else np.zeros((0, 1))
+        self.K_XsXs = np.block([[self.K_XsXs, kq], [kq.T, QQard(xs, xs, self.alpha, self.ell)]])  # :72-73
+        m, K = self.joint()
+        i = self.i
+        cm, cv = self._condMVN(m, K, [i - 1], list(range(i - 1)), self.dot_Xs)              # :80-81
+        mu, var = float(np.ravel(cm)[0]), float(np.ravel(cv)[0])
+        dot_xs = mu + (var if self.compat_sd else np.sqrt(var)) * float(z)                   # :83
+        self.i += 1                                                                          # :86
+        self.Xs = np.vstack([self.Xs, xs])
+        self.dot_Xs = np.append(self.dot_Xs, dot_xs)
+        return {"mu": mu, "sigma": var, "dot_xs": dot_xs}                                    # :92

@@ -75,3 +75,19 @@ get_ml_from_grid <- function(values, alpha, rho_vec, sigma_vec) {
   idx <- which(values == max(values, na.rm = TRUE), arr.ind = TRUE)[1, ]
   list(alpha = alpha, rho = rho_vec[idx[1]], sigma = sigma_vec[idx[2]])
 }
+
+# create_p_dotXnS(Xn_list, mn, Kn, theta): R/ode_gp_library.R:43-93, same closure, same return
+# list(mu, sigma, dot_xs); the O(N^3) algebra of :55-57 runs once on the GPU, a call reads the
+# Cholesky factor and one N x N matrix instead of re-solving for every star point so far.
+# rnorm(1, condMean, condVar) is kept exactly as the reference writes it (:83).
+create_p_dotXnS <- function(Xn_list, mn, Kn, theta, max_steps = 256L) {
+  X <- do.call(cbind, Xn_list)
+  h <- .Call("gpmi_R_seq_create", as.matrix(X), as.double(mn), as.matrix(Kn), theta[[1]], as.double(theta[[2]]),
+             1e-6, as.integer(max_steps))
+  p_dotXnS <- function(xs_vec) {
+    r <- .Call("gpmi_R_seq_step", h, as.double(xs_vec))
+    dot_xs <- rnorm(1, r[1], r[2])
+    .Call("gpmi_R_seq_commit", h, dot_xs)
+    list(mu = r[1], sigma = r[2], dot_xs = dot_xs)
+  }
+}

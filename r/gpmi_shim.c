@@ -216,3 +216,42 @@ SEXP gpmi_R_potrf(SEXP A)
     check(rc);
     return L;
 }
+
+/* create_p_dotXnS(Xn_list, mn, Kn, theta): R/ode_gp_library.R:43-93.  The sampler lives behind an
+ * external pointer whose finalizer releases the device memory; step/commit are the two halves of
+ * one closure call (the draw in between is R's own rnorm, so R's RNG stream is the reference's). */
+static void seq_finalizer(SEXP ptr)
+{
+    gpmi_seq *q = (gpmi_seq *)R_ExternalPtrAddr(ptr);
+    if (q) gpmi_seq_destroy(q);
+    R_ClearExternalPtr(ptr);
+}
+
+SEXP gpmi_R_seq_create(SEXP X, SEXP mn, SEXP Kn, SEXP alpha, SEXP ell, SEXP jitter, SEXP max_steps)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X);
+    gpmi_seq *q = NULL;
+    int rc = gpmi_seq_create(ctx(), &q, REAL(X), n, n, D, REAL(mn), REAL(Kn), n, Rf_asReal(alpha), REAL(ell),
+                             Rf_length(ell), Rf_asReal(jitter), Rf_asInteger(max_steps));
+    check(rc); /* nothing to release on failure: gpmi_seq_create frees what it allocated */
+    SEXP ptr = PROTECT(R_MakeExternalPtr(q, R_NilValue, R_NilValue));
+    R_RegisterCFinalizerEx(ptr, seq_finalizer, TRUE);
+    UNPROTECT(1);
+    return ptr;
+}
+
+SEXP gpmi_R_seq_step(SEXP ptr, SEXP xs)
+{
+    gpmi_seq *q = (gpmi_seq *)R_ExternalPtrAddr(ptr);
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, 2)); /* condMean, condVar */
+    int rc = gpmi_seq_step(q, REAL(xs), REAL(out));
+    UNPROTECT(1);
+    check(rc);
+    return out;
+}
+
+SEXP gpmi_R_seq_commit(SEXP ptr, SEXP dot_xs)
+{
+    check(gpmi_seq_commit((gpmi_seq *)R_ExternalPtrAddr(ptr), Rf_asReal(dot_xs)));
+    return R_NilValue;
+}

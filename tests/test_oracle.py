@@ -191,3 +191,39 @@ def test_logml_grad_matches_finite_differences(orc):
           (orc.logml(X, y, a, r + h, s)[0] - orc.logml(X, y, a, r - h, s)[0]) / (2 * h),
           (orc.logml(X, y, a, r, s + h)[0] - orc.logml(X, y, a, r, s - h)[0]) / (2 * h)]
     np.testing.assert_allclose(g, fd, rtol=2e-7)
+
+
+def _seq_case(orc, n=40, D=1, seed=3):
+    rng = np.random.default_rng(seed)
+    X = np.sort(rng.uniform(0, n * 0.9, size=(n, D)), axis=0)
+    t = np.linspace(0, 6, n)
+    mn, Kn = orc.p_dotXn(t, np.sin(t), 1.0, 0.9, 0.1)
+    return X, mn, Kn
+
+
+def test_seq_sampler_chain_equals_joint(orc):
+    """Pin of the create_p_dotXnS restatement (R/ode_gp_library.R:43-93): the conditionals it
+    returns call by call must be those of the final joint N(m, K) obtained independently by a
+    Cholesky factor of K (mu_i = m_i + l.w, var_i = L_ii^2), and the closure's bookkeeping
+    (i, Xs, dot_Xs) must follow the calls."""
+    import scipy.linalg
+    X, mn, Kn = _seq_case(orc)
+    s = orc.create_p_dotXnS([X[:, 0]], mn, Kn, 1.3, 0.8)
+    pts = [3.1, 10.2, 3.4, 25.0, 17.7, 10.2001]
+    zs = [0.3, -1.1, 0.7, 0.2, -0.4, 1.5]
+    got = [s([p], z) for p, z in zip(pts, zs)]
+    assert s.i == len(pts) + 1 and s.Xs.shape == (len(pts), 1)
+    m, K = s.joint()
+    L = scipy.linalg.cholesky(K, lower=True)
+    w = scipy.linalg.solve_triangular(L, s.dot_Xs - m, lower=True)
+    for i, g in enumerate(got):
+        mu = m[i] + L[i, :i] @ w[:i]
+        assert abs(g["mu"] - mu) <= 1e-9 * max(1.0, abs(mu))
+        assert abs(g["sigma"] - L[i, i] ** 2) <= 1e-9 * max(1e-3, L[i, i] ** 2)
+        assert g["dot_xs"] == g["mu"] + np.sqrt(g["sigma"]) * zs[i]
+    # a state visited twice: the second draw is pinned to the first within the 1e-6 jitters
+    assert abs(got[5]["mu"] - got[1]["dot_xs"]) < 1e-2 and got[5]["sigma"] < 1e-4
+    # :83 as written: the variance is used as the standard deviation
+    c = orc.create_p_dotXnS([X[:, 0]], mn, Kn, 1.3, 0.8, compat_sd=True)
+    r = c([3.1], 0.3)
+    assert r["dot_xs"] == r["mu"] + r["sigma"] * 0.3
