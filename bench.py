@@ -37,6 +37,33 @@ def cpu_baseline(n_sample, D, cores=1):
     return dt, lm[0]
 
 
+def cpu_lapack(n_sample, D, threads):
+    """Best-effort CPU leg: the same evaluation with numpy + LAPACK
+    dpotrf / dtrtrs (scipy, OpenBLAS) on `threads` host threads -- an upper bound for what a CPU
+    build of the reference's path could reach, next to the single-threaded restatement."""
+    import scipy.linalg as sla
+    from threadpoolctl import threadpool_limits
+    from oracle import oracle as orc
+    X, y = orc.synth(n_sample, D)
+    with threadpool_limits(limits=threads):
+        t0 = time.perf_counter()
+        G = X @ X.T
+        sq = np.diag(G).copy()
+        G *= -2.0
+        G += sq[:, None]
+        G += sq[None, :]
+        np.maximum(G, 0.0, out=G)
+        G *= -0.5 / (0.3 * 0.3)
+        np.exp(G, out=G)
+        G[np.diag_indices(n_sample)] += 0.1 * 0.1
+        L = sla.cholesky(G, lower=True, overwrite_a=True, check_finite=False)
+        z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+        sld = float(np.sum(np.log(np.diag(L))))
+        lm = -0.5 * float(z @ z) - sld - 0.5 * n_sample * np.log(2.0 * np.pi)
+        dt = time.perf_counter() - t0
+    return dt, lm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +318,16 @@ def main():
                 "sample_rel_err_gpu_vs_cpu": abs(lm_gpu - lm_cpu) / abs(lm_cpu),
                 "host_cores_available": os.cpu_count(),
             }
+            try:
+                thr = min(16, os.cpu_count() or 1)   # the CPU share of a one-GPU box
+                dt2, lm2 = cpu_lapack(ns, D, thr)
+                line["cpu_baseline"]["lapack_multicore"] = {
+                    "value": 1.0 / (dt2 * scale), "unit": "evals/s", "cores": thr,
+                    "sample": "numpy + LAPACK dpotrf/dtrtrs (scipy, OpenBLAS) at N=%d (%.2f s), scaled by "
+                              "(N/Ns)^3; upper bound for a CPU build, not the reference's path" % (ns, dt2),
+                    "sample_rel_err_vs_oracle": abs(lm2 - lm_cpu) / abs(lm_cpu)}
+            except Exception as e:  # optional leg: never fails the bench line
+                line["cpu_baseline"]["lapack_multicore"] = {"error": repr(e)}
         print(json.dumps(line))
         sys.stdout.flush()
     if distributed:

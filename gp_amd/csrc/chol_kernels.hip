@@ -606,7 +606,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     stagger_start(smem, stagger);
     int ti, tj;
     if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order & 0xff, ti, tj)) return;
+        // order bit 8: the panel is UPPER TRIANGULAR (P[i][k] = 0 for k < i, e.g. L^-T): the
+        // products of tile (ti, tj), tj <= ti, start at column ti * 128 -- a third of the work of
+        // the full update; row-major tile order runs the long tiles first
+        if (order & 0x100) {
+            const int k0 = ti * GT;
+            A += (size_t)k0 * lda;
+            B += (size_t)k0 * ldb;
+            K -= k0;
+        }
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1185,10 +1194,16 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
 
 int g_diag_waves = 5;    // 5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
 int g_syrk_persist = 0;  // 0: one workgroup per tile; 1: persistent workgroups; 2: persistent + CU reservation
+int g_nb_adapt = 1;      // auto outer-block width chosen per block from the columns still to factor
 
 static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
-                              int N, int K, int *ctr, int ncu)
+                              int N, int K, int *ctr, int ncu, int tri = 0)
 {
+    if (tri && M > 0 && N > 0 && K > 0) {  // upper-triangular panel: plain kernel, row-major tiles, zero K-range skipped
+        const int T = (M + GT - 1) / GT;
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(syrk_grid(T, 0)), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, 0x100, 0);
+        return;
+    }
     if (M <= 0 || N <= 0 || K <= 0) return;
     const int T = (M + GT - 1) / GT;
     const int ntiles = syrk_grid(T, g_syrk_order);
@@ -1219,39 +1234,81 @@ void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, si
     launch_syrk_lower(s, P, ldp, C, ldc, m, m, k, ctr, ncu);
 }
 
+// C(lower) -= U U^T for an upper-triangular n x n U
+void launch_syrk_uut(hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n)
+{
+    launch_syrk_lower(s, U, ldu, C, ldc, n, n, n, nullptr, 0, 1);
+}
+
+int g_block_recursive = 1;  // 1: in-block updates by recursive halving; 0: 128 / 256 / rest-of-block levels
+
+// One 128-column panel [k, k + kb): diagonal block, then the rows [max(k + kb, row_lo), row_hi) below it.
+static void panel_one(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int k, int kb,
+                      int row_lo, int row_hi, bool with_diag, hipStream_t s)
+{
+    const int NB = GPMI_NB;
+    double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK
+                           : c->Fpack + (size_t)(((k - ko) / NB) % GPMI_FPACK_SLOTS) * GPMI_FPACK;
+    if (with_diag) {
+        if (g_diag_waves == 4)
+            hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
+        else
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
+    }
+    const int r0 = k + kb;
+    const int rlo = r0 > row_lo ? r0 : row_lo;
+    if (rlo >= row_hi) return;
+    hipLaunchKernelGGL(k_trsm_panel, dim3((row_hi - rlo + 63) / 64), 256, 0, s, W + (size_t)k * ld, ld, rlo, row_hi, kb, Fp);
+}
+
+// Columns [k0, k1) by recursive halving at panel boundaries: factor the left half, update the
+// right half with it in ONE product (K = width of the left half: 128, 256, 512 for a 1024-column
+// block), factor the right half.  Compared with fixed 128 / 256 levels the same flops move from
+// K = 256 products to a K = 512 one, whose per-tile prologue and C round trip weigh half as much.
+static void panel_rec(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int k0, int k1,
+                      int row_lo, int row_hi, bool with_diag, hipStream_t s)
+{
+    const int NB = GPMI_NB;
+    if (k1 - k0 <= NB) {
+        panel_one(c, W, ld, d_info, Fpack_all, ko, k0, k1 - k0, row_lo, row_hi, with_diag, s);
+        return;
+    }
+    const int npan = (k1 - k0 + NB - 1) / NB;
+    const int km = k0 + ((npan + 1) / 2) * NB;
+    panel_rec(c, W, ld, d_info, Fpack_all, ko, k0, km, row_lo, row_hi, with_diag, s);
+    const int rlo = km > row_lo ? km : row_lo;
+    if (rlo < row_hi)  // rows [rlo, row_hi) x cols [km, k1) -= A[rows, k0:km] A[km:k1, k0:km]^T
+        launch_gemm_nt(s, W + (size_t)rlo + (size_t)k0 * ld, ld, W + (size_t)km + (size_t)k0 * ld, ld,
+                       W + (size_t)rlo + (size_t)km * ld, ld, row_hi - rlo, k1 - km, km - k0, 1);
+    panel_rec(c, W, ld, d_info, Fpack_all, ko, km, k1, row_lo, row_hi, with_diag, s);
+}
+
 // Panel work of one outer block [ko, ke) restricted to the rows [row_lo, row_hi) below each
-// panel.  Three blocking levels: 128-column panels, grouped into middle blocks of NBM columns.
-// A panel's K = 128 update reaches only to the end of its middle block; the rest of the outer
-// block is updated once per middle block with K = NBM (the K = 128 GEMM runs at ~60 % of the
-// K = 256 one's rate).  with_diag: also factor the 128 x 128 diagonal blocks (their factors go
-// to the block's Fpack slots); without it the slots written by an earlier call are used.
+// panel.  with_diag: also factor the 128 x 128 diagonal blocks (their factors go to the block's
+// Fpack slots); without it the slots written by an earlier call are used.
 //   (0, M, true)   : the whole panel phase, full height
 //   (0, ke, true)  : only the NBO x NBO diagonal block -- the latency chain of the look-ahead
 //   (ke, M, false) : the rows below it -- wide, throughput-bound kernels
+// g_block_recursive == 0 keeps the earlier three fixed levels: 128-column panels grouped into
+// middle blocks of NBM columns; a panel's K = 128 update reaches only to the end of its middle
+// block, the rest of the outer block is updated once per middle block with K = NBM.
 static void panel_rows(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int ke, int NBO,
                        int row_lo, int row_hi, bool with_diag, hipStream_t s)
 {
+    if (g_block_recursive) {
+        panel_rec(c, W, ld, d_info, Fpack_all, ko, ko, ke, row_lo, row_hi, with_diag, s);
+        return;
+    }
     const int NB = GPMI_NB;
     const int NBM = (NBO >= 512) ? 256 : NBO;
     for (int km = ko; km < ke; km += NBM) {
         const int kme = (km + NBM < ke) ? km + NBM : ke;
         for (int k = km; k < kme; k += NB) {
             const int kb = (kme - k < NB) ? kme - k : NB;
-            double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK
-                                   : c->Fpack + (size_t)(((k - ko) / NB) % GPMI_FPACK_SLOTS) * GPMI_FPACK;
-            if (with_diag) {
-                if (g_diag_waves == 4)
-                    hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
-                                       d_info, k);
-                else
-                    hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp,
-                                       d_info, k);
-            }
+            panel_one(c, W, ld, d_info, Fpack_all, ko, k, kb, row_lo, row_hi, with_diag, s);
             const int r0 = k + kb;
             const int rlo = r0 > row_lo ? r0 : row_lo;
             if (rlo >= row_hi) continue;
-            hipLaunchKernelGGL(k_trsm_panel, dim3((row_hi - rlo + 63) / 64), 256, 0, s, W + (size_t)k * ld, ld, rlo,
-                               row_hi, kb, Fp);
             if (r0 < kme)  // rest of this middle block: rows [rlo, row_hi) x cols [r0, kme), K = kb
                 launch_gemm_nt(s, W + (size_t)rlo + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
                                W + (size_t)rlo + (size_t)r0 * ld, ld, row_hi - rlo, kme - r0, kb, 1);
@@ -1270,14 +1327,18 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     // trapezoid in W; the trailing [nfac, ncol) part receives the Schur complement.
     // outer block width: K of the trailing update.  Wider blocks cut the C traffic and the
     // number of epilogues once the trailing matrix is large; 256 keeps the panel phase short.
-    const int NBO = c->nb_outer > 0 ? c->nb_outer : (nfac >= 12288 ? 1024 : (nfac >= 6144 ? 512 : 256));
+    auto nbo_for = [](int cols) { return cols >= 12288 ? 1024 : (cols >= 6144 ? 512 : 256); };
+    const int NBO = c->nb_outer > 0 ? c->nb_outer : nbo_for(nfac);
     const bool la = c->lookahead > 0 && c->pstream && nfac > NBO && NBO / GPMI_NB <= GPMI_FPACK_SLOTS;
     if (!la) {
         hipStream_t s = c->stream;
-        for (int ko = 0; ko < nfac; ko += NBO) {
-            const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
+        // auto width follows the columns still to factor (g_nb_adapt): the last blocks of a large
+        // matrix are a small matrix, whose few trailing tiles do not fill the chip at K = 1024
+        for (int ko = 0, nbo = NBO; ko < nfac; ko += nbo) {
+            nbo = (c->nb_outer > 0 || !g_nb_adapt) ? NBO : nbo_for(nfac - ko);
+            const int ke = (ko + nbo < nfac) ? ko + nbo : nfac;
             kt_begin(c, 2, s);
-            panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, NBO, 0, M, true, s);
+            panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, nbo, 0, M, true, s);
             kt_end(c, 2, 0.0, s);
             if (ke >= M || ke >= ncol) continue;
             const double mt = (double)(ncol - ke), extra = (double)(M - ncol);

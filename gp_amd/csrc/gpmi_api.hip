@@ -352,6 +352,16 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         g_syrk_persist = value;
         return 0;
     }
+    if (!strcmp(name, "block_recursive")) {
+        extern int g_block_recursive;
+        g_block_recursive = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "nb_adapt")) {
+        extern int g_nb_adapt;
+        g_nb_adapt = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "syrk_order")) {
         extern int g_syrk_order;
         g_syrk_order = value;
@@ -1243,6 +1253,7 @@ __global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ 
 
 void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
                        int ncu);
+void launch_syrk_uut(hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n);
 
 extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
                                double alpha, const double *ell, int n_ell, double sigma, double jitter,
@@ -1281,7 +1292,7 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     hipLaunchKernelGGL(k_upper_mv, dim3((n + 255) / 256), 256, 0, s, U, ldu, n, zv, av);
     // W(lower) = -U U^T = -K^-1
     HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
-    launch_syrk_probe(s, U, ldu, c->W, ld, n, n, c->d_ctr, c->ncu);
+    launch_syrk_uut(s, U, ldu, c->W, ld, n);
     hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, n, p, av, c->W, ld, part);
     hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, sums);
     HIPCHK(hipGetLastError());
