@@ -171,12 +171,13 @@ __global__ __launch_bounds__(320) void k_potrf_diag(double *__restrict__ A, size
 // microseconds instead of waiting for a whole CU to drain by chance (5 waves need two wave
 // slots with ~200 registers each on one SIMD, which a resident SYRK wave rules out).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, size_t lda, int nb_act,
-                                                     double *__restrict__ Fpack, int *info, int col0)
+constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 16 * 17;  // doubles of workgroup memory the body needs (50 KB)
+__device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double *__restrict__ A, size_t lda, int nb_act,
+                                                 double *__restrict__ Fpack, int *info, int col0)
 {
-    __shared__ double s_pub[2][8][256];
-    __shared__ double s_inv[8][256];
-    __shared__ double s_d16[16][17];
+    double (*s_pub)[8][256] = reinterpret_cast<double (*)[8][256]>(sm);
+    double (*s_inv)[256] = reinterpret_cast<double (*)[256]>(sm + 2 * 8 * 256);
+    double (*s_d16)[17] = reinterpret_cast<double (*)[17]>(sm + 2 * 8 * 256 + 8 * 256);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
@@ -281,6 +282,13 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, 
 #undef GPMI_SOLVE_ROW
 #undef GPMI_UPDATE_ROW
 #undef GPMI_STORE_ROW
+}
+
+__global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, size_t lda, int nb_act,
+                                                     double *__restrict__ Fpack, int *info, int col0)
+{
+    __shared__ double sm[DIAG4_LDS];
+    potrf_diag4_body(sm, A, lda, nb_act, Fpack, info, col0);
 }
 
 // ---------------------------------------------------------------------------
@@ -592,12 +600,25 @@ __device__ __forceinline__ void stagger_start(double (&smem)[2][2][GK][GP], int 
     }
 }
 
+// Fused look-ahead: the workgroup of tile (0, 0) -- the 128 x 128 diagonal block of the NEXT panel
+// whenever the update starts at the row of its first column -- factors that block as soon as its
+// own tile is stored, while the other workgroups of the launch are still updating.  The
+// diagonal-block latency chain (27 us per panel) then runs inside the update instead of after
+// it, needs no launch and no free CU of its own, and the panel solve follows directly.
+struct FuseDiag {
+    double *Fp;   // packed-factor slot of that panel; nullptr: no fusion
+    int *info;
+    int col0;     // global column of the block (for info)
+    int nb;       // active order of the block (<= 128)
+};
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
                                                  const double *__restrict__ B, size_t ldb,
                                                  double *__restrict__ C, size_t ldc, int M, int N, int K, int order,
-                                                 int stagger)
+                                                 int stagger, FuseDiag fd)
 {
+    static_assert(2 * 2 * GK * GP >= DIAG4_LDS, "the diagonal-block body runs in the staging buffer");
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
     // bits 24+ of `stagger` are probe-only switches (tools/syrk_bench.py): 1 = skip the C
     // epilogue, 2 = skip the operand streaming of the main loop; used for the cost breakdown
@@ -621,6 +642,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         tj = blockIdx.y;
     }
     gemm_tile<MODE>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, (int)threadIdx.x);
+    if (MODE != 2 && fd.Fp && ti == 0 && tj == 0) {  // workgroup-uniform
+        // the tile's stores must be visible to the other waves of this workgroup, which read the
+        // block back in the diagonal kernel's register layout
+        __threadfence();
+        __syncthreads();
+        __threadfence();
+        potrf_diag4_body(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+    }
 }
 
 // Persistent SYRK: at most two workgroups per CU are launched and each pulls tiles from a
@@ -1187,33 +1216,49 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
         return;
     }
     if (accumulate_minus)
-        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0);
+        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{});
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0);
+        hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{});
+}
+
+int g_fuse_diag = 1;  // 1: the next panel's diagonal block is factored inside the update that completes it
+
+// C -= A B^T with the default kernel and the diagonal block at C's origin factored by the
+// workgroup of tile (0, 0).  false: this configuration cannot fuse (caller launches the
+// diagonal kernel itself and uses launch_gemm_nt).
+static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb, double *C,
+                                 size_t ldc, int M, int N, int K, const FuseDiag &fd)
+{
+    if (!g_fuse_diag || (g_gemm_variant != 3 && g_gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
+    dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
+    hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, fd);
+    return true;
 }
 
 int g_diag_waves = 5;    // 5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
 int g_syrk_persist = 0;  // 0: one workgroup per tile; 1: persistent workgroups; 2: persistent + CU reservation
 int g_nb_adapt = 1;      // auto outer-block width chosen per block from the columns still to factor
 
-static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
-                              int N, int K, int *ctr, int ncu, int tri = 0)
+// returns true when fd was given and the launch factors the diagonal block at C's origin
+static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
+                              int N, int K, int *ctr, int ncu, int tri = 0, const FuseDiag *fd = nullptr)
 {
     if (tri && M > 0 && N > 0 && K > 0) {  // upper-triangular panel: plain kernel, row-major tiles, zero K-range skipped
         const int T = (M + GT - 1) / GT;
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(syrk_grid(T, 0)), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, 0x100, 0);
-        return;
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(syrk_grid(T, 0)), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, 0x100, 0,
+                           FuseDiag{});
+        return false;
     }
-    if (M <= 0 || N <= 0 || K <= 0) return;
+    if (M <= 0 || N <= 0 || K <= 0) return false;
     const int T = (M + GT - 1) / GT;
     const int ntiles = syrk_grid(T, g_syrk_order);
     if (g_gemm_variant == 2) {
         hipLaunchKernelGGL(k_gemm9<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
-        return;
+        return false;
     }
     if (g_gemm_variant == 1) {
         hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
-        return;
+        return false;
     }
     const int stg = ntiles >= 1024 ? g_stagger : 0;  // only when every CU holds two workgroups for many rounds
     if (g_syrk_persist && ctr) {
@@ -1223,9 +1268,13 @@ static void launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
         const int budget = (g_syrk_persist == 2 && ntiles >= 2 * slots) ? 16 : 0;
         hipLaunchKernelGGL(k_syrk_persist, dim3(grid), 256, 0, s, P, ldp, C, ldc, M, N, K, g_syrk_order, stg, ntiles,
                            budget, ctr);
-        return;
+        return false;
     }
-    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg);
+    // tile (0, 0) is block 0 only in the row-major order
+    const bool fuse = fd && fd->Fp && g_fuse_diag && g_syrk_order == 0;
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg,
+                       fuse ? *fd : FuseDiag{});
+    return fuse;
 }
 
 void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
@@ -1243,12 +1292,16 @@ void launch_syrk_uut(hipStream_t s, const double *U, size_t ldu, double *C, size
 int g_block_recursive = 1;  // 1: in-block updates by recursive halving; 0: 128 / 256 / rest-of-block levels
 
 // One 128-column panel [k, k + kb): diagonal block, then the rows [max(k + kb, row_lo), row_hi) below it.
+static double *fpack_slot(gpmi_ctx *c, double *Fpack_all, int ko, int k)
+{
+    return Fpack_all ? Fpack_all + (size_t)(k / GPMI_NB) * GPMI_FPACK
+                     : c->Fpack + (size_t)(((k - ko) / GPMI_NB) % GPMI_FPACK_SLOTS) * GPMI_FPACK;
+}
+
 static void panel_one(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int k, int kb,
                       int row_lo, int row_hi, bool with_diag, hipStream_t s)
 {
-    const int NB = GPMI_NB;
-    double *Fp = Fpack_all ? Fpack_all + (size_t)(k / NB) * GPMI_FPACK
-                           : c->Fpack + (size_t)(((k - ko) / NB) % GPMI_FPACK_SLOTS) * GPMI_FPACK;
+    double *Fp = fpack_slot(c, Fpack_all, ko, k);
     if (with_diag) {
         if (g_diag_waves == 4)
             hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
@@ -1266,21 +1319,29 @@ static void panel_one(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
 // block), factor the right half.  Compared with fixed 128 / 256 levels the same flops move from
 // K = 256 products to a K = 512 one, whose per-tile prologue and C round trip weigh half as much.
 static void panel_rec(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int k0, int k1,
-                      int row_lo, int row_hi, bool with_diag, hipStream_t s)
+                      int row_lo, int row_hi, bool with_diag, bool first_diag_done, hipStream_t s)
 {
     const int NB = GPMI_NB;
     if (k1 - k0 <= NB) {
-        panel_one(c, W, ld, d_info, Fpack_all, ko, k0, k1 - k0, row_lo, row_hi, with_diag, s);
+        panel_one(c, W, ld, d_info, Fpack_all, ko, k0, k1 - k0, row_lo, row_hi, with_diag && !first_diag_done, s);
         return;
     }
     const int npan = (k1 - k0 + NB - 1) / NB;
     const int km = k0 + ((npan + 1) / 2) * NB;
-    panel_rec(c, W, ld, d_info, Fpack_all, ko, k0, km, row_lo, row_hi, with_diag, s);
+    panel_rec(c, W, ld, d_info, Fpack_all, ko, k0, km, row_lo, row_hi, with_diag, first_diag_done, s);
     const int rlo = km > row_lo ? km : row_lo;
-    if (rlo < row_hi)  // rows [rlo, row_hi) x cols [km, k1) -= A[rows, k0:km] A[km:k1, k0:km]^T
-        launch_gemm_nt(s, W + (size_t)rlo + (size_t)k0 * ld, ld, W + (size_t)km + (size_t)k0 * ld, ld,
-                       W + (size_t)rlo + (size_t)km * ld, ld, row_hi - rlo, k1 - km, km - k0, 1);
-    panel_rec(c, W, ld, d_info, Fpack_all, ko, km, k1, row_lo, row_hi, with_diag, s);
+    bool fused = false;
+    if (rlo < row_hi) {  // rows [rlo, row_hi) x cols [km, k1) -= A[rows, k0:km] A[km:k1, k0:km]^T
+        const double *A = W + (size_t)rlo + (size_t)k0 * ld, *B = W + (size_t)km + (size_t)k0 * ld;
+        double *C = W + (size_t)rlo + (size_t)km * ld;
+        if (with_diag && rlo == km) {  // C starts at the next panel's diagonal block: factor it in this launch
+            const int kb = (k1 - km < NB) ? k1 - km : NB;
+            fused = launch_gemm_nt_fused(s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0,
+                                         FuseDiag{fpack_slot(c, Fpack_all, ko, km), d_info, km, kb});
+        }
+        if (!fused) launch_gemm_nt(s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0, 1);
+    }
+    panel_rec(c, W, ld, d_info, Fpack_all, ko, km, k1, row_lo, row_hi, with_diag, fused, s);
 }
 
 // Panel work of one outer block [ko, ke) restricted to the rows [row_lo, row_hi) below each
@@ -1293,10 +1354,10 @@ static void panel_rec(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
 // middle blocks of NBM columns; a panel's K = 128 update reaches only to the end of its middle
 // block, the rest of the outer block is updated once per middle block with K = NBM.
 static void panel_rows(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int ke, int NBO,
-                       int row_lo, int row_hi, bool with_diag, hipStream_t s)
+                       int row_lo, int row_hi, bool with_diag, hipStream_t s, bool first_diag_done = false)
 {
     if (g_block_recursive) {
-        panel_rec(c, W, ld, d_info, Fpack_all, ko, ko, ke, row_lo, row_hi, with_diag, s);
+        panel_rec(c, W, ld, d_info, Fpack_all, ko, ko, ke, row_lo, row_hi, with_diag, first_diag_done, s);
         return;
     }
     const int NB = GPMI_NB;
@@ -1305,7 +1366,7 @@ static void panel_rows(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *F
         const int kme = (km + NBM < ke) ? km + NBM : ke;
         for (int k = km; k < kme; k += NB) {
             const int kb = (kme - k < NB) ? kme - k : NB;
-            panel_one(c, W, ld, d_info, Fpack_all, ko, k, kb, row_lo, row_hi, with_diag, s);
+            panel_one(c, W, ld, d_info, Fpack_all, ko, k, kb, row_lo, row_hi, with_diag && !(first_diag_done && k == ko), s);
             const int r0 = k + kb;
             const int rlo = r0 > row_lo ? r0 : row_lo;
             if (rlo >= row_hi) continue;
@@ -1334,17 +1395,22 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
         hipStream_t s = c->stream;
         // auto width follows the columns still to factor (g_nb_adapt): the last blocks of a large
         // matrix are a small matrix, whose few trailing tiles do not fill the chip at K = 1024
+        bool diag_done = false;
         for (int ko = 0, nbo = NBO; ko < nfac; ko += nbo) {
             nbo = (c->nb_outer > 0 || !g_nb_adapt) ? NBO : nbo_for(nfac - ko);
             const int ke = (ko + nbo < nfac) ? ko + nbo : nfac;
             kt_begin(c, 2, s);
-            panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, nbo, 0, M, true, s);
+            panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, nbo, 0, M, true, s, diag_done);
             kt_end(c, 2, 0.0, s);
+            diag_done = false;
             if (ke >= M || ke >= ncol) continue;
             const double mt = (double)(ncol - ke), extra = (double)(M - ncol);
+            // the first diagonal block of the next outer block rides in this trailing update
+            FuseDiag fd{};
+            if (ke < nfac) fd = FuseDiag{fpack_slot(c, Fpack_all, ke, ke), d_info, ke, (nfac - ke < GPMI_NB) ? nfac - ke : GPMI_NB};
             kt_begin(c, 1, s);
-            launch_syrk_lower(s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld, M - ke,
-                              ncol - ke, ke - ko, c->d_ctr, c->ncu);
+            diag_done = launch_syrk_lower(s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
+                                          M - ke, ncol - ke, ke - ko, c->d_ctr, c->ncu, 0, &fd);
             // algorithmic flops: lower triangle (incl. diagonal) of the square part + extra rows
             kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(ke - ko), s);
         }

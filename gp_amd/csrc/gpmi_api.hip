@@ -352,6 +352,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         g_syrk_persist = value;
         return 0;
     }
+    if (!strcmp(name, "fuse_diag")) {
+        extern int g_fuse_diag;
+        g_fuse_diag = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "block_recursive")) {
         extern int g_block_recursive;
         g_block_recursive = value != 0;
