@@ -1221,7 +1221,13 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
         hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{});
 }
 
-int g_fuse_diag = 1;  // 1: the next panel's diagonal block is factored inside the update that completes it
+// the next panel's diagonal block is factored inside the update that completes it -- bit 0: in-block
+// GEMMs, bit 1: the trailing SYRK (multi-round launches only).  Measured with 4 grid lanes (N = 16384 /
+// 8192, ms per evaluation): off 25.0 / 4.12, GEMMs only 25.25 / 4.12, SYRK only 24.95 / 4.07, both
+// 24.55 / 4.02 -- with both, no one-workgroup kernel is left that has to find a free CU next to the
+// other lanes' updates.  One evaluation at a time: neutral (the block's tile sits on the critical
+// path either way).
+int g_fuse_diag = 3;
 
 // C -= A B^T with the default kernel and the diagonal block at C's origin factored by the
 // workgroup of tile (0, 0).  false: this configuration cannot fuse (caller launches the
@@ -1229,7 +1235,7 @@ int g_fuse_diag = 1;  // 1: the next panel's diagonal block is factored inside t
 static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb, double *C,
                                  size_t ldc, int M, int N, int K, const FuseDiag &fd)
 {
-    if (!g_fuse_diag || (g_gemm_variant != 3 && g_gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
+    if (!(g_fuse_diag & 1) || (g_gemm_variant != 3 && g_gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
     hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, fd);
     return true;
@@ -1237,7 +1243,7 @@ static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, con
 
 int g_diag_waves = 5;    // 5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
 int g_syrk_persist = 0;  // 0: one workgroup per tile; 1: persistent workgroups; 2: persistent + CU reservation
-int g_nb_adapt = 1;      // auto outer-block width chosen per block from the columns still to factor
+int g_nb_adapt = 0;      // 1: auto outer-block width chosen per block from the columns still to factor (measured: -0.2 ms sequential at N = 16384, nothing with lanes)
 
 // returns true when fd was given and the launch factors the diagonal block at C's origin
 static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
@@ -1271,7 +1277,9 @@ static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
         return false;
     }
     // tile (0, 0) is block 0 only in the row-major order
-    const bool fuse = fd && fd->Fp && g_fuse_diag && g_syrk_order == 0;
+    // only in launches of more than one round of tiles, where workgroup 0's extra 27 us do not
+    // lengthen the kernel
+    const bool fuse = fd && fd->Fp && (g_fuse_diag & 2) && g_syrk_order == 0 && ntiles > 2 * (ncu > 0 ? ncu : 256);
     hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg,
                        fuse ? *fd : FuseDiag{});
     return fuse;

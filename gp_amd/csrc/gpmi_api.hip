@@ -354,7 +354,7 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     }
     if (!strcmp(name, "fuse_diag")) {
         extern int g_fuse_diag;
-        g_fuse_diag = value != 0;
+        g_fuse_diag = value;
         return 0;
     }
     if (!strcmp(name, "block_recursive")) {
