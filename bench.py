@@ -67,7 +67,7 @@ def cpu_lapack(n_sample, D, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--d", type=int, default=3)

@@ -610,7 +610,66 @@ struct FuseDiag {
     int *info;
     int col0;     // global column of the block (for info)
     int nb;       // active order of the block (<= 128)
+    int *ctr;     // zeroed device counter for the sub-tiled variant (order bit 9)
 };
+
+// 64 x 64 sub-tile of C -= A B^T at (sm0, sn0), one workgroup, fragments straight from global
+// memory (L2-resident panel), no LDS, no barriers: wave w owns the 32 x 32 block (w & 1, w >> 1)
+// as 2 x 2 MFMA tiles, operands of 8 k-groups in flight behind the 8 being multiplied.
+// Requires K % 32 == 0 and the sub-tile wholly inside C.
+__device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t lda, const double *__restrict__ B,
+                                           size_t ldb, double *__restrict__ C, size_t ldc, int K, int sm0, int sn0)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int mb = sm0 + (w & 1) * 32, nb = sn0 + (w >> 1) * 32;
+    const double *pa = A + (size_t)(mb + lr) + (size_t)lq * lda;  // bf[tm] = pa[tm * 16 + k * lda]
+    const double *pb = B + (size_t)(nb + lr) + (size_t)lq * ldb;  // af[tn] = pb[tn * 16 + k * ldb]
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    double fa[2][8][2], fb[2][8][2];
+    auto load = [&](int set, int k0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[set][g][t] = pb[t * 16 + (size_t)(k0 + 4 * g) * ldb];
+                fb[set][g][t] = pa[t * 16 + (size_t)(k0 + 4 * g) * lda];
+            }
+    };
+    auto mul = [&](int set) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma(fa[set][g][tn], fb[set][g][tm], acc[tn][tm]);
+    };
+    load(0, 0);
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        if (k0 + 32 < K) load(1, k0 + 32);
+        mul(0);
+        if (k0 + 32 < K) {
+            if (k0 + 64 < K) load(0, k0 + 64);
+            mul(1);
+        }
+    }
+    double *cb = C + (size_t)(mb + lr) + (size_t)(nb + lq) * ldc;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double *q = cb + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc;
+                *q = *q - acc[tn][tm][i];
+            }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
@@ -637,12 +696,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
             B += (size_t)k0 * ldb;
             K -= k0;
         }
+    } else if (MODE == 0 && (order & 0x200)) {
+        // Sub-tiled fused launch (1-D grid): the diagonal tile (0, 0) sits on the critical path of
+        // the panel chain and one workgroup needs K * 256 cycles for it, so its lower triangle is
+        // cut into three 64 x 64 sub-tiles on three CUs (blocks 0..2, dispatched first); block 0
+        // waits for the other two and factors the block.  Blocks >= 3 are the tiles 1, 2, ...
+        const int b = blockIdx.x;
+        if (b < 3) {
+            gemm_sub64(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0);
+            __threadfence();
+            __syncthreads();
+            if (b) {
+                if (threadIdx.x == 0) atomicAdd(fd.ctr, 1);
+                return;
+            }
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(fd.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2)
+                    __builtin_amdgcn_s_sleep(4);
+                __hip_atomic_store(fd.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
+            }
+            __syncthreads();
+            __threadfence();
+            potrf_diag4_body(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+            return;
+        }
+        const int gx = (M + GT - 1) / GT;
+        ti = (b - 2) % gx;
+        tj = (b - 2) / gx;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
     }
     gemm_tile<MODE>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, (int)threadIdx.x);
-    if (MODE != 2 && fd.Fp && ti == 0 && tj == 0) {  // workgroup-uniform
+    if (MODE != 2 && fd.Fp && !(order & 0x200) && ti == 0 && tj == 0) {  // workgroup-uniform
         // the tile's stores must be visible to the other waves of this workgroup, which read the
         // block back in the diagonal kernel's register layout
         __threadfence();
@@ -1227,7 +1313,7 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
 // 24.55 / 4.02 -- with both, no one-workgroup kernel is left that has to find a free CU next to the
 // other lanes' updates.  One evaluation at a time: neutral (the block's tile sits on the critical
 // path either way).
-int g_fuse_diag = 3;
+int g_fuse_diag = 7;  // bit 2: sub-tiled diagonal tile in the fused in-block GEMMs
 
 // C -= A B^T with the default kernel and the diagonal block at C's origin factored by the
 // workgroup of tile (0, 0).  false: this configuration cannot fuse (caller launches the
@@ -1237,6 +1323,10 @@ static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, con
 {
     if (!(g_fuse_diag & 1) || (g_gemm_variant != 3 && g_gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
+    if ((g_fuse_diag & 4) && fd.ctr && M >= GT && N >= GT && K % 32 == 0) {  // tile (0, 0) interior: sub-tiled
+        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(grid.x * grid.y + 2), 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0x200, 0, fd);
+        return true;
+    }
     hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, fd);
     return true;
 }
@@ -1345,7 +1435,7 @@ static void panel_rec(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
         if (with_diag && rlo == km) {  // C starts at the next panel's diagonal block: factor it in this launch
             const int kb = (k1 - km < NB) ? k1 - km : NB;
             fused = launch_gemm_nt_fused(s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0,
-                                         FuseDiag{fpack_slot(c, Fpack_all, ko, km), d_info, km, kb});
+                                         FuseDiag{fpack_slot(c, Fpack_all, ko, km), d_info, km, kb, c->d_ctr + 8});
         }
         if (!fused) launch_gemm_nt(s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0, 1);
     }
@@ -1415,7 +1505,8 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             const double mt = (double)(ncol - ke), extra = (double)(M - ncol);
             // the first diagonal block of the next outer block rides in this trailing update
             FuseDiag fd{};
-            if (ke < nfac) fd = FuseDiag{fpack_slot(c, Fpack_all, ke, ke), d_info, ke, (nfac - ke < GPMI_NB) ? nfac - ke : GPMI_NB};
+            if (ke < nfac)
+                fd = FuseDiag{fpack_slot(c, Fpack_all, ke, ke), d_info, ke, (nfac - ke < GPMI_NB) ? nfac - ke : GPMI_NB, nullptr};
             kt_begin(c, 1, s);
             diag_done = launch_syrk_lower(s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
                                           M - ke, ncol - ke, ke - ko, c->d_ctr, c->ncu, 0, &fd);
