@@ -230,30 +230,52 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
         }                                                                                              \
     }
 
+    // The only tile the next pivot block waits for is the diagonal tile of block-row kb + 1: its
+    // owner updates it first (EARLY) and hands it to the factor wave; every other update of step kb
+    // (REST) runs in the next iteration between B1 and B2, i.e. under the factor wave's 4.4 k cycles.
+#define GPMI_UPDATE_EARLY(T, NJ, br, X)                                                                \
+    {                                                                                                  \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
+            T[GPMI_CL(kb + 1, NJ)] = mfma(s_pub[kb & 1][kb + 1][kg * 64 + lane], X[kg], T[GPMI_CL(kb + 1, NJ)]); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = T[GPMI_CL(kb + 1, NJ)][i]; \
+    }
+#define GPMI_UPDATE_REST(T, NJ, br, X)                                                                 \
+    _Pragma("unroll") for (int jb = kb; jb < (NJ); ++jb) {                                             \
+        if (jb <= (br) && !(jb == kb && (br) == kb)) {                                                 \
+            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                           \
+                T[jb] = mfma(s_pub[(kb - 1) & 1][jb][kg * 64 + lane], X[kg], T[jb]);                   \
+        }                                                                                              \
+    }
+
+    d4 XA[8], XB[8], XC[8];
+    if (rc == 0) {  // block-row 0 hands tile (0, 0) to the factor wave in matrix order
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TC[0][i];
+    }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        // (a) the owner hands its updated diagonal tile to the factor wave in matrix order
-        if (ra == kb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TA[kb][i];
-        } else if (rb == kb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TB[GPMI_CL(kb, 5)][i];
-        } else if (rc == kb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TC[GPMI_CL(kb, 2)][i];
+        __syncthreads();  // B1: diagonal tile kb is in s_d16
+        if (kb > 0) {     // REST of step kb - 1: tiles jb >= kb of the rows below, except tile (kb, kb)
+            if (ra >= kb) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
+            if (rb >= kb) { GPMI_UPDATE_REST(TB, 5, rb, XB[kb - 1]) }
+            if (rc >= kb) { GPMI_UPDATE_REST(TC, 2, rc, XC[kb - 1]) }
         }
-        __syncthreads();  // B1
         __syncthreads();  // B2: factor wave done
-        d4 XA = d4{0.0, 0.0, 0.0, 0.0}, XB = XA, XC = XA;
-        GPMI_SOLVE_ROW(TA, 8, ra, XA)
-        GPMI_SOLVE_ROW(TB, 5, rb, XB)
-        GPMI_SOLVE_ROW(TC, 2, rc, XC)
-        __syncthreads();  // B3
-        if (ra > kb) { GPMI_UPDATE_ROW(TA, 8, ra, XA) }
-        if (rb > kb) { GPMI_UPDATE_ROW(TB, 5, rb, XB) }
-        if (rc > kb) { GPMI_UPDATE_ROW(TC, 2, rc, XC) }
+        XA[kb] = d4{0.0, 0.0, 0.0, 0.0};
+        XB[kb] = XA[kb];
+        XC[kb] = XA[kb];
+        GPMI_SOLVE_ROW(TA, 8, ra, XA[kb])
+        GPMI_SOLVE_ROW(TB, 5, rb, XB[kb])
+        GPMI_SOLVE_ROW(TC, 2, rc, XC[kb])
+        __syncthreads();  // B3: -X tiles published
+        if (kb < 7) {     // EARLY: the next diagonal tile
+            if (ra == kb + 1) GPMI_UPDATE_EARLY(TA, 8, ra, XA[kb])
+            else if (rb == kb + 1) GPMI_UPDATE_EARLY(TB, 5, rb, XB[kb])
+            else if (rc == kb + 1) GPMI_UPDATE_EARLY(TC, 2, rc, XC[kb])
+        }
     }
+#undef GPMI_UPDATE_EARLY
+#undef GPMI_UPDATE_REST
 
 #define GPMI_STORE_ROW(T, NJ, br)                                                                      \
     _Pragma("unroll") for (int jb = 0; jb < (NJ); ++jb) {                                              \

@@ -129,3 +129,35 @@ def test_grid_lanes_match_single_evaluations(ctx, orc):
         assert np.all(info == 0)
         for g in (0, 3, 6):
             assert out[g, 0] == ctx.logml(X, y, 1.0, [rho[g]], sig[g])[0]  # bit-identical
+
+
+@pytest.mark.parametrize("n,nbo", [(2500, 1024), (1333, 512), (1153, 0)])
+def test_fused_diagonal_modes_agree(ctx, orc, n, nbo):
+    """The fused look-ahead variants (diagonal block factored inside the update that completes it;
+    its tile cut into three sub-tiles on three CUs; option fuse_diag bits 0..2) and the recursive /
+    fixed-level in-block blockings are re-orderings of the same factorisation: every combination
+    must give the LAPACK result (1e-10 relative on logml, far inside the 1e-8 bar), also with
+    ragged last panels and a forced 1024-wide outer block (K = 512 sub-tiles)."""
+    import scipy.linalg as sla
+    X, y = orc.synth(n, 2, seed=n)
+    K = orc.QQard(X, X, 1.0, [0.2]) + 0.01 * np.eye(n)
+    L = sla.cholesky(K, lower=True); z = sla.solve_triangular(L, y, lower=True)
+    want = -0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * n * math.log(2 * math.pi)
+    try:
+        ctx.set_option("nb_outer", nbo)
+        for rec in (1, 0):
+            ctx.set_option("block_recursive", rec)
+            for mode in (0, 1, 2, 3, 7):
+                ctx.set_option("fuse_diag", mode)
+                got = ctx.logml(X, y, 1.0, [0.2], 0.1)
+                assert abs(got[0] - want) <= 1e-10 * abs(want), (rec, mode, got[0], want)
+        # a non-PD matrix is still reported at the right order through the fused paths
+        ctx.set_option("fuse_diag", 7); ctx.set_option("block_recursive", 1)
+        A = K.copy(); k = 1100 if n > 1200 else 300
+        A[k, k] = -1.0
+        import gp_amd
+        with pytest.raises(gp_amd.NotPositiveDefinite) as e:
+            ctx.potrf(A)
+        assert e.value.order == k + 1
+    finally:
+        ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 7); ctx.set_option("block_recursive", 1)
