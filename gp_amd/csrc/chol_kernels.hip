@@ -638,16 +638,27 @@ struct FuseDiag {
 // 64 x 64 sub-tile of C -= A B^T at (sm0, sn0), one workgroup, fragments straight from global
 // memory (L2-resident panel), no LDS, no barriers: wave w owns the 32 x 32 block (w & 1, w >> 1)
 // as 2 x 2 MFMA tiles, operands of 8 k-groups in flight behind the 8 being multiplied.
-// Requires K % 32 == 0 and the sub-tile wholly inside C.
+// Requires K % 32 == 0.  mv / nv: valid rows of A / B counted from the tile origin (operand rows
+// past them are clamped, outputs past them dropped).
 __device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t lda, const double *__restrict__ B,
-                                           size_t ldb, double *__restrict__ C, size_t ldc, int K, int sm0, int sn0)
+                                           size_t ldb, double *__restrict__ C, size_t ldc, int K, int sm0, int sn0,
+                                           int mv, int nv)
 {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int mb = sm0 + (w & 1) * 32, nb = sn0 + (w >> 1) * 32;
-    const double *pa = A + (size_t)(mb + lr) + (size_t)lq * lda;  // bf[tm] = pa[tm * 16 + k * lda]
-    const double *pb = B + (size_t)(nb + lr) + (size_t)lq * ldb;  // af[tn] = pb[tn * 16 + k * ldb]
+    if (mb >= mv || nb >= nv) return;  // wave-uniform
+    int ra[2], rb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ra[t] = mb + t * 16 + lr;
+        ra[t] = ra[t] < mv ? ra[t] : mv - 1;
+        rb[t] = nb + t * 16 + lr;
+        rb[t] = rb[t] < nv ? rb[t] : nv - 1;
+    }
+    const double *pa = A + (size_t)lq * lda;  // bf[tm] = pa[ra[tm] + k * lda]
+    const double *pb = B + (size_t)lq * ldb;  // af[tn] = pb[rb[tn] + k * ldb]
     d4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -659,8 +670,8 @@ __device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t 
         for (int g = 0; g < 8; ++g)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fa[set][g][t] = pb[t * 16 + (size_t)(k0 + 4 * g) * ldb];
-                fb[set][g][t] = pa[t * 16 + (size_t)(k0 + 4 * g) * lda];
+                fa[set][g][t] = pb[rb[t] + (size_t)(k0 + 4 * g) * ldb];
+                fb[set][g][t] = pa[ra[t] + (size_t)(k0 + 4 * g) * lda];
             }
     };
     auto mul = [&](int set) {
@@ -681,23 +692,122 @@ __device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t 
             mul(1);
         }
     }
-    double *cb = C + (size_t)(mb + lr) + (size_t)(nb + lq) * ldc;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                double *q = cb + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc;
-                *q = *q - acc[tn][tm][i];
+                const int m = mb + tm * 16 + lr, n = nb + tn * 16 + lq + 4 * i;
+                if (m < mv && n < nv) {
+                    double *q = C + (size_t)m + (size_t)n * ldc;
+                    *q = *q - acc[tn][tm][i];
+                }
             }
 }
+
+// 64 x 64 tile of C -= A B^T, LDS-staged: the quadrant kernel of the SYRK tail split.  Four waves
+// x (2 x 2 MFMA tiles), k-step 16, two LDS stages filled through registers (16-B global loads,
+// ds_write_b128; row pad 16 doubles: k and k + 1 on opposite bank halves as in the big tile).
+// A, B point at the quadrant's first operand rows; mv / nv valid rows from there (clamped loads,
+// dropped outputs).  K % 16 == 0.
+constexpr int QP = 80;  // padded row of the quadrant's LDS image
+__device__ __forceinline__ void gemm_quad64(double *__restrict__ sm, const double *__restrict__ A, size_t lda,
+                                            const double *__restrict__ B, size_t ldb, double *__restrict__ C,
+                                            size_t ldc, int K, int mv, int nv, int tid)
+{
+    double (*q)[2][GK][QP] = reinterpret_cast<double (*)[2][GK][QP]>(sm);  // [stage][op][k][row]
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int mb = (w & 1) * 32, nb = (w >> 1) * 32;
+    // staging: thread handles the row pair r2 of k-rows kr and kr + 8 of both operands
+    const int r2 = tid & 31, kr = tid >> 5;
+    const bool fast = (mv >= 64) && (nv >= 64);
+    int ra0 = 2 * r2, ra1 = 2 * r2 + 1, rb0 = ra0, rb1 = ra1;
+    ra0 = ra0 < mv ? ra0 : mv - 1;
+    ra1 = ra1 < mv ? ra1 : mv - 1;
+    rb0 = rb0 < nv ? rb0 : nv - 1;
+    rb1 = rb1 < nv ? rb1 : nv - 1;
+    double2 va[2], vb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t ca = (size_t)(k0 + kr + 8 * j) * lda, cb = (size_t)(k0 + kr + 8 * j) * ldb;
+            if (fast) {
+                va[j] = *reinterpret_cast<const double2 *>(A + 2 * r2 + ca);
+                vb[j] = *reinterpret_cast<const double2 *>(B + 2 * r2 + cb);
+            } else {
+                va[j] = make_double2(A[ra0 + ca], A[ra1 + ca]);
+                vb[j] = make_double2(B[rb0 + cb], B[rb1 + cb]);
+            }
+        }
+    };
+    auto swrite = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<double2 *>(&q[st][0][kr + 8 * j][2 * r2]) = va[j];
+            *reinterpret_cast<double2 *>(&q[st][1][kr + 8 * j][2 * r2]) = vb[j];
+        }
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    const int nk = K / GK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GK);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = q[st][1][kk * 4 + lq][nb + t * 16 + lr];
+                bf[t] = q[st][0][kk * 4 + lq][mb + t * 16 + lr];
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
+        }
+        if (kt + 1 < nk) swrite(st ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mb + tm * 16 + lr, n = nb + tn * 16 + lq + 4 * i;
+                if (m < mv && n < nv) {
+                    double *c = C + (size_t)m + (size_t)n * ldc;
+                    *c = *c - acc[tn][tm][i];
+                }
+            }
+}
+
+// Tail split of a SYRK launch: the R < slots tiles of the last, partial round would hold R
+// workgroup slots for a whole tile time while the rest of the chip idles.  Each of them is cut
+// into its four 64 x 64 quadrants (blocks bfull + 4 t + q), computed by gemm_quad64: independent
+// outputs, no exchange between workgroups, the same sums in the same order as timing-independent
+// code must have.
+struct KSplit {
+    int bfull;   // blocks below this index are whole tiles
+    int S;       // 4: quadrants; <= 1: no split
+};
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
                                                  const double *__restrict__ B, size_t ldb,
                                                  double *__restrict__ C, size_t ldc, int M, int N, int K, int order,
-                                                 int stagger, FuseDiag fd)
+                                                 int stagger, FuseDiag fd, KSplit ks)
 {
     static_assert(2 * 2 * GK * GP >= DIAG4_LDS, "the diagonal-block body runs in the staging buffer");
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
@@ -708,7 +818,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     stagger_start(smem, stagger);
     int ti, tj;
     if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order & 0xff, ti, tj)) return;
+        int b = blockIdx.x;
+        if (ks.S > 1 && b >= ks.bfull) {
+            const int q = b - ks.bfull;
+            if (!syrk_tile(ks.bfull + (q >> 2), (M + GT - 1) / GT, order & 0xff, ti, tj)) return;
+            const int qm = q & 1, qn = (q >> 1) & 1;
+            if (ti == tj && qn > qm) return;  // strictly upper quadrant of a diagonal tile
+            const int m0 = ti * GT + qm * 64, n0 = tj * GT + qn * 64;
+            if (m0 >= M || n0 >= N) return;
+            gemm_quad64(&smem[0][0][0][0], A + m0, lda, B + n0, ldb, C + (size_t)m0 + (size_t)n0 * ldc, ldc, K, M - m0,
+                        N - n0, (int)threadIdx.x);
+            return;
+        }
+        if (!syrk_tile(b, (M + GT - 1) / GT, order & 0xff, ti, tj)) return;
         // order bit 8: the panel is UPPER TRIANGULAR (P[i][k] = 0 for k < i, e.g. L^-T): the
         // products of tile (ti, tj), tj <= ti, start at column ti * 128 -- a third of the work of
         // the full update; row-major tile order runs the long tiles first
@@ -725,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         // waits for the other two and factors the block.  Blocks >= 3 are the tiles 1, 2, ...
         const int b = blockIdx.x;
         if (b < 3) {
-            gemm_sub64(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0);
+            gemm_sub64(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0, GT, GT);
             __threadfence();
             __syncthreads();
             if (b) {
@@ -1324,9 +1446,9 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
         return;
     }
     if (accumulate_minus)
-        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{});
+        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{}, KSplit{});
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{});
+        hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{}, KSplit{});
 }
 
 // the next panel's diagonal block is factored inside the update that completes it -- bit 0: in-block
@@ -1346,10 +1468,10 @@ static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, con
     if (!(g_fuse_diag & 1) || (g_gemm_variant != 3 && g_gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
     if ((g_fuse_diag & 4) && fd.ctr && M >= GT && N >= GT && K % 32 == 0) {  // tile (0, 0) interior: sub-tiled
-        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(grid.x * grid.y + 2), 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0x200, 0, fd);
+        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(grid.x * grid.y + 2), 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0x200, 0, fd, KSplit{});
         return true;
     }
-    hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, fd);
+    hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, fd, KSplit{});
     return true;
 }
 
@@ -1358,13 +1480,20 @@ int g_syrk_persist = 0;  // 0: one workgroup per tile; 1: persistent workgroups;
 int g_nb_adapt = 0;      // 1: auto outer-block width chosen per block from the columns still to factor (measured: -0.2 ms sequential at N = 16384, nothing with lanes)
 
 // returns true when fd was given and the launch factors the diagonal block at C's origin
+int g_ksplit = 1;        // quadrant split of the tail-round tiles of a SYRK launch (see KSplit)
+// ... when at most this many tiles are left for the last round.  Whole tiles of a round this thin run
+// alone on their CUs (~115 us at K = 1024 instead of ~250 us shared); four quadrant workgroups take
+// ~75 us as long as they, too, have CUs of their own (4 R <= ~400).  Measured per launch (K = 1024):
+// R = 16..92: -0.04 .. -0.065 ms; R = 136..340: +0.03 .. +0.06 ms.
+int g_ksplit_max = 100;
+
 static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
                               int N, int K, int *ctr, int ncu, int tri = 0, const FuseDiag *fd = nullptr)
 {
     if (tri && M > 0 && N > 0 && K > 0) {  // upper-triangular panel: plain kernel, row-major tiles, zero K-range skipped
         const int T = (M + GT - 1) / GT;
         hipLaunchKernelGGL(k_gemm_nt<1>, dim3(syrk_grid(T, 0)), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, 0x100, 0,
-                           FuseDiag{});
+                           FuseDiag{}, KSplit{});
         return false;
     }
     if (M <= 0 || N <= 0 || K <= 0) return false;
@@ -1391,9 +1520,19 @@ static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
     // tile (0, 0) is block 0 only in the row-major order
     // only in launches of more than one round of tiles, where workgroup 0's extra 27 us do not
     // lengthen the kernel
-    const bool fuse = fd && fd->Fp && (g_fuse_diag & 2) && g_syrk_order == 0 && ntiles > 2 * (ncu > 0 ? ncu : 256);
-    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ntiles), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg,
-                       fuse ? *fd : FuseDiag{});
+    const int slots = 2 * (ncu > 0 ? ncu : 256);
+    const bool fuse = fd && fd->Fp && (g_fuse_diag & 2) && g_syrk_order == 0 && ntiles > slots;
+    KSplit ks{};
+    int grid = ntiles;
+    if (g_ksplit && g_syrk_order == 0 && K % GK == 0) {
+        const int bfull = (ntiles / slots) * slots, R = ntiles - bfull;
+        if (R > 0 && R <= g_ksplit_max) {
+            ks = KSplit{bfull, 4};
+            grid = bfull + 4 * R;
+        }
+    }
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(grid), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg,
+                       fuse ? *fd : FuseDiag{}, ks);
     return fuse;
 }
 

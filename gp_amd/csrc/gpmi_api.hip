@@ -244,8 +244,8 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
     }
     HIPCHK(hipMalloc((void **)&c->Fpack, (size_t)GPMI_FPACK_SLOTS * GPMI_FPACK * sizeof(double)));
     HIPCHK(hipMalloc((void **)&c->d_info, 64));
-    HIPCHK(hipMalloc((void **)&c->d_ctr, 64));
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, 64, c->own_stream));
+    HIPCHK(hipMalloc((void **)&c->d_ctr, 2048));
+    HIPCHK(hipMemsetAsync(c->d_ctr, 0, 2048, c->own_stream));
     HIPCHK(hipStreamSynchronize(c->own_stream));
     c->ncu = prop.multiProcessorCount;
     HIPCHK(hipMalloc((void **)&c->d_out, 64));
@@ -350,6 +350,12 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     if (!strcmp(name, "syrk_persist")) {
         extern int g_syrk_persist;
         g_syrk_persist = value;
+        return 0;
+    }
+    if (!strcmp(name, "ksplit")) {  // 0: off; 1: on; R > 1: on, split the tail round when it holds <= R tiles
+        extern int g_ksplit, g_ksplit_max;
+        g_ksplit = value != 0;
+        if (value > 1) g_ksplit_max = value;
         return 0;
     }
     if (!strcmp(name, "fuse_diag")) {

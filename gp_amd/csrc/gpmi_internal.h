@@ -31,7 +31,8 @@ struct gpmi_ctx {
     double *scratch;         // small device scratch (results, staging)
     size_t scratch_bytes;
     int *d_info;
-    int *d_ctr;              // zeroed counters of the persistent trailing-update kernel (tile, retired, early exits)
+    int *d_ctr;              // zeroed counters: [0..2] persistent trailing update (tile, retired, early exits),
+                             // [8] sub-tile counter of the fused in-block GEMM
     int ncu;                 // compute units of the device
     double *d_out;           // 3 doubles
     // generic device staging buffers for the host-pointer API
