@@ -763,18 +763,21 @@ __device__ __forceinline__ void gemm_quad64(double *__restrict__ sm, const doubl
     for (int kt = 0; kt < nk; ++kt) {
         const int st = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * GK);
+        if (mb < mv && nb < nv) {  // wave-uniform: a wave whose block lies outside the matrix only stages
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            double af[2], bf[2];
+            for (int kk = 0; kk < 4; ++kk) {
+                double af[2], bf[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = q[st][1][kk * 4 + lq][nb + t * 16 + lr];
-                bf[t] = q[st][0][kk * 4 + lq][mb + t * 16 + lr];
+                for (int t = 0; t < 2; ++t) {
+                    af[t] = q[st][1][kk * 4 + lq][nb + t * 16 + lr];
+                    bf[t] = q[st][0][kk * 4 + lq][mb + t * 16 + lr];
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        if (mb + tm * 16 < mv && nb + tn * 16 < nv) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
             }
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
         }
         if (kt + 1 < nk) swrite(st ^ 1);
         __syncthreads();
@@ -1525,10 +1528,18 @@ static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
     KSplit ks{};
     int grid = ntiles;
     if (g_ksplit && g_syrk_order == 0 && K % GK == 0) {
+        int first = ntiles;  // first tile computed as quadrants
         const int bfull = (ntiles / slots) * slots, R = ntiles - bfull;
-        if (R > 0 && R <= g_ksplit_max) {
-            ks = KSplit{bfull, 4};
-            grid = bfull + 4 * R;
+        if (R > 0 && R <= g_ksplit_max) first = bfull;
+        // A last tile row with few valid rows -- the augmented row y^T of the marginal likelihood makes
+        // every trailing update end in a row of T tiles with ONE valid row -- costs a whole tile time
+        // per tile (2.4 % of all tiles at N = 16384); as quadrants only the MFMA tiles that hold
+        // valid rows are multiplied (1/8 of the work).
+        const int vlast = M - (T - 1) * GT;
+        if (T > 1 && vlast <= 64 && ntiles - T < first) first = ntiles - T;
+        if (first < ntiles) {
+            ks = KSplit{first, 4};
+            grid = first + 4 * (ntiles - first);
         }
     }
     hipLaunchKernelGGL(k_gemm_nt<1>, dim3(grid), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg,
