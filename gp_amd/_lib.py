@@ -48,6 +48,29 @@ class NotPositiveDefinite(GpmiError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as ROCm's).  If libgpmi pulls in
+    ROCm's copy first and torch is imported later, the process ends up with two HIP/HSA runtimes and
+    torch finds no GPU.  When torch is installed but not yet loaded, map ITS runtime first so that
+    both libraries share one; without torch (e.g. under R) libgpmi uses ROCm's as linked."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libgpmi.so; loud failure when it has not been built."""
     global _lib
@@ -56,6 +79,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GpmiError(-4, "%s not found: build it with `python -m gp_amd._build` "
                         "(hipcc --offload-arch=gfx950); gp_amd has no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     lib.gpmi_last_error.restype = C.c_char_p
     for name in SYMBOLS:

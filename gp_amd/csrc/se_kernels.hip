@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int TILE = 64;
+constexpr int SE_TR = 64, SE_TC = 8 * (512 / SE_TR);  // tile of k_se_cov<>: 256 threads x (2 rows, 8 columns)
 
 __device__ __forceinline__ void store_pair(double *p, double v0, double v1, bool ok0, bool ok1, bool vec)
 {
@@ -27,17 +28,53 @@ __device__ __forceinline__ void store_pair(double *p, double v0, double v1, bool
     }
 }
 
+// exp(x) for x <= 0 (the argument of the squared-exponential kernel).  Argument reduction
+// x = n ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 in r (remainder < 5e-18
+// relative), result = ldexp(p, n); <= 1 ulp of error like the library routine.  What it drops is
+// the library's overflow / infinity handling (x > 0 never happens; x < -800 is clamped and
+// underflows to 0 through ldexp) and, above all, its code shape: the coefficients come from
+// constant memory into SGPRs and every Horner step is ONE v_fma_f64 -- the library's fmac form
+// needs two v_mov_b32 per coefficient and element (19 of 60 VALU instructions per element of
+// the build kernel), which made an HBM-write-bound kernel half compute-bound.
+struct ExpC {
+    double c[18];
+};
+// passed as a kernel argument: values the compiler cannot see stay in SGPRs (constants it can see
+// are re-materialised with v_mov in front of every fmac)
+static const ExpC h_exp = {{
+    1.4426950408889634074,        // log2(e)
+    -6.93147180369123816490e-01,  // -ln2 high part (32 trailing zero bits: n * hi is exact)
+    -1.90821492927058770002e-10,  // -ln2 low part
+    1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+    1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0,
+    -800.0}};
+__device__ __forceinline__ double exp_nonpos(double x, const ExpC &e)
+{
+    x = fmax(x, e.c[17]);
+    const double n = rint(x * e.c[0]);
+    double r = fma(n, e.c[1], x);
+    r = fma(n, e.c[2], r);
+    double p = e.c[3];
+#pragma unroll
+    for (int k = 4; k <= 16; ++k) p = fma(p, r, e.c[k]);
+    return ldexp(p, (int)n);
+}
+
 // K[i,j] = a2 * exp(-1/2 sum_d ((X[i,d]-Y[j,d]) * inv_ell[d])^2), diag_add on i == j if same.
 template <int DT>
 __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, int n, int ldx,
                                                 const double *__restrict__ Y, int m, int ldy,
                                                 SeParams p, double diag_add, int same, int lower,
-                                                double *__restrict__ K, size_t ldk, int vec)
+                                                double *__restrict__ K, size_t ldk, int vec, ExpC ec)
 {
     const int D = (DT > 0) ? DT : p.D;
-    const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
-    if (lower && col0 > row0 + TILE - 1) return;  // tile strictly above the diagonal
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // SE_TR x SE_TC = 64 x 64 tile per workgroup.  Measured (N = 16384, lower triangle, 1.07 GB, with
+    // the lean exp above): 64 x 64 0.220 ms = 4.89 TB/s; 128 x 32 0.237; 32 x 128 0.232; 512 x 8
+    // (4 KiB contiguous per column) 0.310; a 1-D grid over the lower-triangular tiles only 0.237 -
+    // 0.280 depending on the walk.  With the library exp the 64 x 64 tile took 0.228 ms.
+    const int row0 = blockIdx.x * SE_TR, col0 = blockIdx.y * SE_TC;
+    if (lower && col0 > row0 + SE_TR - 1) return;  // tile strictly above the diagonal
+    const int tx = threadIdx.x & (SE_TR / 2 - 1), ty = threadIdx.x / (SE_TR / 2);
     const int r = row0 + 2 * tx;
     const bool ok0 = r < n, ok1 = r + 1 < n;
     double x0[GPMI_MAXD], x1[GPMI_MAXD];
@@ -64,7 +101,7 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
                 s1 = fma(d1, d1, s1);
             }
         }
-        double v0 = p.a2 * exp(-0.5 * s0), v1 = p.a2 * exp(-0.5 * s1);
+        double v0 = p.a2 * exp_nonpos(-0.5 * s0, ec), v1 = p.a2 * exp_nonpos(-0.5 * s1, ec);
         if (same) {
             if (r == c) v0 = p.a2 + diag_add;  // Stan: diagonal exactly alpha^2 (+ sigma^2)
             if (r + 1 == c) v1 = p.a2 + diag_add;
@@ -79,7 +116,7 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
 __global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X, int n, int ldx,
                                                     const double *__restrict__ Y, int m, int ldy,
                                                     SeParams p, double diag_add, int same, int lower,
-                                                    double *__restrict__ K, size_t ldk, int vec)
+                                                    double *__restrict__ K, size_t ldk, int vec, ExpC ec)
 {
     const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
     if (lower && col0 > row0 + TILE - 1) return;
@@ -99,7 +136,7 @@ __global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X
             s0 = fma(d0, d0, s0);
             s1 = fma(d1, d1, s1);
         }
-        double v0 = p.a2 * exp(-0.5 * s0), v1 = p.a2 * exp(-0.5 * s1);
+        double v0 = p.a2 * exp_nonpos(-0.5 * s0, ec), v1 = p.a2 * exp_nonpos(-0.5 * s1, ec);
         if (same) {
             if (r == c) v0 = p.a2 + diag_add;
             if (r + 1 == c) v1 = p.a2 + diag_add;
@@ -348,16 +385,17 @@ void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double
     const int same = (dY == nullptr);
     if (same) { dY = dX; ldy = ldx; }
     dim3 grid((n + TILE - 1) / TILE, (m + TILE - 1) / TILE);
+    if (p.D <= GPMI_MAXD) grid = dim3((n + SE_TR - 1) / SE_TR, (m + SE_TC - 1) / SE_TC);  // k_se_cov<>
     const int vec = vec_ok(dK, ldk);
     switch (p.D) {
-    case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
-    case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
-    case 3: hipLaunchKernelGGL(k_se_cov<3>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec); break;
+    case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
+    case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
+    case 3: hipLaunchKernelGGL(k_se_cov<3>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
     default:
         if (p.D <= GPMI_MAXD)
-            hipLaunchKernelGGL(k_se_cov<0>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec);
+            hipLaunchKernelGGL(k_se_cov<0>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp);
         else
-            hipLaunchKernelGGL(k_se_cov_big, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec);
+            hipLaunchKernelGGL(k_se_cov_big, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp);
         break;
     }
 }
