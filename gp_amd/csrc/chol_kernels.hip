@@ -31,6 +31,15 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// C-tile accesses of the update kernels: dbg bit 3 (probe) makes them non-temporal so that the
+// streamed C tiles do not displace the panel operands, which every tile re-reads, from L2
+__device__ __forceinline__ double ld_c(const double *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_c(double *p, double v, bool nt)
+{
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 __device__ __forceinline__ double readlane64(double v, int l)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -525,6 +534,7 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
     const bool interior = (m0 + GT <= M) && (n0 + GT <= N);
     double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 64 + lq) * ldc;
     double ch[2][4][4];
+    const bool cnt = (dbg & 8) != 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (MODE != 2 && interior) {
@@ -533,7 +543,7 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ch[tn][tm][i] = cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc];
+                for (int i = 0; i < 4; ++i) ch[tn][tm][i] = ld_c(cbase + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc, cnt);
     }
     compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK);
     if (dbg & 1) {
@@ -554,8 +564,8 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    cbase[tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc] =
-                        (MODE == 2) ? acc[tn][tm][i] : ch[tn][tm][i] - acc[tn][tm][i];
+                    st_c(cbase + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc,
+                         (MODE == 2) ? acc[tn][tm][i] : ch[tn][tm][i] - acc[tn][tm][i], cnt);
         if (MODE != 2) {
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
@@ -563,7 +573,7 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
                 for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        ch[tn][tm][i] = cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc];
+                        ch[tn][tm][i] = ld_c(cbase + tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc, cnt);
         }
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
@@ -571,8 +581,8 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    cbase[tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc] =
-                        (MODE == 2) ? acc[tn + 2][tm][i] : ch[tn][tm][i] - acc[tn + 2][tm][i];
+                    st_c(cbase + tm * 16 + (size_t)((tn + 2) * 16 + 4 * i) * ldc,
+                         (MODE == 2) ? acc[tn + 2][tm][i] : ch[tn][tm][i] - acc[tn + 2][tm][i], cnt);
         return;
     }
 
