@@ -180,7 +180,16 @@ __global__ __launch_bounds__(320) void k_potrf_diag(double *__restrict__ A, size
 // microseconds instead of waiting for a whole CU to drain by chance (5 waves need two wave
 // slots with ~200 registers each on one SIMD, which a resident SYRK wave rules out).
 // ---------------------------------------------------------------------------
+template <bool COH>
+__device__ __forceinline__ double ld_blk(const double *p)
+{
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
 constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 16 * 17;  // doubles of workgroup memory the body needs (50 KB)
+// COH: the block was written by other workgroups of the same launch with agent-scope stores; read it
+// with agent-scope loads (they do not trust this XCD's L2) instead of invalidating caches with a fence
+template <bool COH = false>
 __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double *__restrict__ A, size_t lda, int nb_act,
                                                  double *__restrict__ Fpack, int *info, int col0)
 {
@@ -214,7 +223,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
                 const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
                 const int rr = row > col ? row : col, cc = row > col ? col : row;                      \
-                T[jb][i] = (rr < nb_act) ? A[(size_t)rr + (size_t)cc * lda] : (row == col ? 1.0 : 0.0); \
+                T[jb][i] = (rr < nb_act) ? ld_blk<COH>(A + (size_t)rr + (size_t)cc * lda) : (row == col ? 1.0 : 0.0); \
             }                                                                                          \
         }                                                                                              \
     }
@@ -652,6 +661,7 @@ struct FuseDiag {
 // as 2 x 2 MFMA tiles, operands of 8 k-groups in flight behind the 8 being multiplied.
 // Requires K % 32 == 0.  mv / nv: valid rows of A / B counted from the tile origin (operand rows
 // past them are clamped, outputs past them dropped).
+template <bool COH = false>
 __device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t lda, const double *__restrict__ B,
                                            size_t ldb, double *__restrict__ C, size_t ldc, int K, int sm0, int sn0,
                                            int mv, int nv)
@@ -713,7 +723,12 @@ __device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t 
                 const int m = mb + tm * 16 + lr, n = nb + tn * 16 + lq + 4 * i;
                 if (m < mv && n < nv) {
                     double *q = C + (size_t)m + (size_t)n * ldc;
-                    *q = *q - acc[tn][tm][i];
+                    const double v = *q - acc[tn][tm][i];
+                    // COH: agent-scope store (written through this XCD's L2): another CU, possibly on
+                    // another XCD, reads the sub-tile in the same launch, and a release FENCE would
+                    // write back the whole L2 instead of these 32 KiB
+                    if constexpr (COH) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *q = v;
                 }
             }
 }
@@ -862,8 +877,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         // waits for the other two and factors the block.  Blocks >= 3 are the tiles 1, 2, ...
         const int b = blockIdx.x;
         if (b < 3) {
-            gemm_sub64(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0, GT, GT);
-            __threadfence();
+            gemm_sub64<true>(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0, GT, GT);
+            // the agent-scope stores above are complete (acknowledged by the memory side) once
+            // vmcnt drains; no cache-wide fence is needed around this hand-over
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (b) {
                 if (threadIdx.x == 0) atomicAdd(fd.ctr, 1);
@@ -875,8 +892,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
                 __hip_atomic_store(fd.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
             }
             __syncthreads();
-            __threadfence();
-            potrf_diag4_body(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+            potrf_diag4_body<true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
             return;
         }
         const int gx = (M + GT - 1) / GT;
