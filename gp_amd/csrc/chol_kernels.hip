@@ -1398,13 +1398,30 @@ __global__ __launch_bounds__(1024) void k_logml_finalize(const double *__restric
 }
 
 // f = L z, one thread per row (rows coalesced across lanes)
-__global__ __launch_bounds__(256) void k_trmv_lower(const double *__restrict__ L, size_t ldl, int n,
-                                                    const double *__restrict__ z, double *__restrict__ f)
+// 512-column chunks on a 2-D grid (a one-thread-per-row loop over all columns is a latency chain at
+// large n), chunks wholly above the diagonal skipped, partial sums added in chunk order
+constexpr int TMV_COLS = 512;
+__global__ __launch_bounds__(256) void k_trmv_lower_part(const double *__restrict__ L, size_t ldl, int n,
+                                                         const double *__restrict__ z, double *__restrict__ part)
+{
+    const int r0 = blockIdx.x * 256, i = r0 + threadIdx.x;
+    const int c0 = blockIdx.y * TMV_COLS;
+    if (i >= n) return;
+    double s = 0.0;
+    if (c0 <= r0 + 255) {
+        const int c1 = (c0 + TMV_COLS - 1 < i) ? c0 + TMV_COLS - 1 : i;  // last column of this chunk for row i
+        for (int k = c0; k <= c1; ++k) s = fma(L[(size_t)i + (size_t)k * ldl], z[k], s);
+    }
+    part[(size_t)blockIdx.y * n + i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_trmv_lower_sum(const double *__restrict__ part, int n, int nchunk,
+                                                        double *__restrict__ f)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double s = 0.0;
-    for (int k = 0; k <= i; ++k) s = fma(L[(size_t)i + (size_t)k * ldl], z[k], s);
+    for (int q = 0; q < nchunk; ++q) s += part[(size_t)q * n + i];
     f[i] = s;
 }
 
@@ -1813,10 +1830,15 @@ void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int
     hipLaunchKernelGGL(k_logml_finalize, dim3(1), 1024, 0, s, W, ld, n, zrow, d_info, d_out3, d_info_out);
 }
 
-void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f)
+int trmv_lower_chunks(int n) { return (n + TMV_COLS - 1) / TMV_COLS; }
+
+// part: trmv_lower_chunks(n) * n doubles of scratch
+void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f, double *part)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_trmv_lower, dim3((n + 255) / 256), 256, 0, s, L, ldl, n, z, f);
+    const int nchunk = trmv_lower_chunks(n);
+    hipLaunchKernelGGL(k_trmv_lower_part, dim3((n + 255) / 256, nchunk), 256, 0, s, L, ldl, n, z, part);
+    hipLaunchKernelGGL(k_trmv_lower_sum, dim3((n + 255) / 256), 256, 0, s, part, n, nchunk, f);
 }
 
 void launch_probe_mfma(hipStream_t s, const double *A, const double *B, double *D)

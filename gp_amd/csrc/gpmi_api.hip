@@ -701,10 +701,10 @@ extern "C" int gpmi_trmv_lower(gpmi_ctx *c, const double *L, int n, int ldl, con
     int rc;
     if ((rc = stage_buf(c, 2, (size_t)n * n * sizeof(double), &dL))) return rc;
     if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dz))) return rc;
-    if ((rc = stage_buf(c, 1, (size_t)n * sizeof(double), &df))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)n * (1 + trmv_lower_chunks(n)) * sizeof(double), &df))) return rc;
     if ((rc = h2d_matrix(c, L, n, n, ldl, dL))) return rc;
     HIPCHK(hipMemcpyAsync(dz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    launch_trmv_lower(c->stream, dL, (size_t)n, n, dz, df);
+    launch_trmv_lower(c->stream, dL, (size_t)n, n, dz, df, df + n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(f, df, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1180,14 +1180,41 @@ __global__ void k_set_identity(double *__restrict__ A, size_t ld, int n)
     }
 }
 
-// a = U z for upper-triangular U (= L^-T): thread = row, columns j >= i
-__global__ __launch_bounds__(256) void k_upper_mv(const double *__restrict__ U, size_t ld, int n,
-                                                  const double *__restrict__ z, double *__restrict__ a)
+// a = U z for upper-triangular U (= L^-T): thread = row, 512-column chunks on a 2-D grid (a
+// one-thread-per-row loop over all columns is a latency chain: 8 ms at N = 16384), chunks wholly
+// below the diagonal skipped, partial sums added in chunk order (fixed: deterministic)
+constexpr int UMV_ROWS = 256, UMV_COLS = 512;
+__global__ __launch_bounds__(UMV_ROWS) void k_upper_mv_part(const double *__restrict__ U, size_t ld, int n,
+                                                            const double *__restrict__ z, double *__restrict__ part)
+{
+    const int r0 = blockIdx.x * UMV_ROWS, i = r0 + threadIdx.x;
+    const int c0 = blockIdx.y * UMV_COLS;
+    const int c1 = (c0 + UMV_COLS < n) ? c0 + UMV_COLS : n;
+    if (i >= n) return;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c1 > r0) {  // some column j >= some row of this block
+        int j = c0 > i ? c0 : i;
+        const double *col = U + (size_t)i + (size_t)j * ld;
+        for (; j + 4 <= c1; j += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fma(col[(size_t)q * ld], z[j + q], acc[q]);
+            col += 4 * ld;
+        }
+        for (; j < c1; ++j) {
+            acc[0] = fma(col[0], z[j], acc[0]);
+            col += ld;
+        }
+    }
+    part[(size_t)blockIdx.y * n + i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__global__ __launch_bounds__(256) void k_upper_mv_sum(const double *__restrict__ part, int n, int nchunk,
+                                                      double *__restrict__ a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double acc = 0.0;
-    for (int j = i; j < n; ++j) acc += U[(size_t)i + (size_t)j * ld] * z[j];
+    for (int q = 0; q < nchunk; ++q) acc += part[(size_t)q * n + i];
     a[i] = acc;
 }
 
@@ -1286,9 +1313,10 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
     double *U, *vec, *Fall;
     if ((rc = stage_buf(c, 2, ldu * (size_t)(n + 1) * sizeof(double), &U))) return rc;
-    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS + ntiles * GRAD_NS) * sizeof(double), &vec))) return rc;
+    const int nchunk = (n + UMV_COLS - 1) / UMV_COLS;
+    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS + ntiles * GRAD_NS + (size_t)nchunk * n) * sizeof(double), &vec))) return rc;
     if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
-    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS;
+    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS, *mvpart = part + ntiles * GRAD_NS;
     hipStream_t s = c->stream;
     // factorisation with the augmented row, all panel factors kept
     HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
@@ -1300,7 +1328,8 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     // U = L^-T, a = U z = K^-1 y
     hipLaunchKernelGGL(k_set_identity, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, ldu, n);
     if ((rc = launch_trsm_right(c, c->W, ld, n, U, ldu, n, Fall, 1))) return rc;
-    hipLaunchKernelGGL(k_upper_mv, dim3((n + 255) / 256), 256, 0, s, U, ldu, n, zv, av);
+    hipLaunchKernelGGL(k_upper_mv_part, dim3((n + UMV_ROWS - 1) / UMV_ROWS, nchunk), UMV_ROWS, 0, s, U, ldu, n, zv, mvpart);
+    hipLaunchKernelGGL(k_upper_mv_sum, dim3((n + 255) / 256), 256, 0, s, mvpart, n, nchunk, av);
     // W(lower) = -U U^T = -K^-1
     HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
     launch_syrk_uut(s, U, ldu, c->W, ld, n);

@@ -127,6 +127,8 @@ void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, doub
 void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0, int m, double scale, double *out);
 void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
                            const int *d_info, double *d_out3, int *d_info_out);
-void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f);
+int trmv_lower_chunks(int n);
+void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f,
+                       double *part /* trmv_lower_chunks(n) * n doubles */);
 void launch_probe_mfma(hipStream_t s, const double *A, const double *B, double *D);
 void launch_probe_peak(hipStream_t s, double *sink, int iters, int *blocks, int *threads);
