@@ -901,6 +901,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
+        if (MODE == 0 && (order & 0x100)) {  // longest tiles (small ti) first: grid is (tj, ti)
+            ti = blockIdx.y;
+            tj = blockIdx.x;
+        }
+        // order bit 8 (plain grid): A is upper-trapezoidal -- A[i][k] = 0 for i > k + koff, koff =
+        // fd.col0 (the global column of A's first column; fd carries no fusion here) -- so the
+        // products of row-tile ti start at its first non-zero column (X L^-T with triangular X)
+        if (MODE == 0 && (order & 0x100)) {
+            const int k0 = ti * GT - fd.col0;
+            if (k0 > 0) {
+                if (k0 >= K) return;
+                A += (size_t)k0 * lda;
+                B += (size_t)k0 * ldb;
+                K -= k0;
+            }
+        }
     }
     gemm_tile<MODE>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, (int)threadIdx.x);
     if (MODE != 2 && fd.Fp && !(order & 0x200) && ti == 0 && tj == 0) {  // workgroup-uniform
@@ -1786,6 +1802,37 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     return 0;
 }
 
+// Columns [c0, c1) of X <- X L^-T by recursive halving at panel boundaries: solve the left half, take
+// it out of the right half in ONE product (K = width of the left half: the bulk of the N^3 flops runs
+// at K in the thousands instead of K = 128), solve the right half.  upper_tri: X[i][j] = 0 for i > j --
+// column block [c0, c1) has rows [0, c1) only, and the product skips the zero columns of its
+// trapezoidal A operand per row-tile.
+static void trsm_right_rec(hipStream_t s, const double *L, size_t ldl, double *X, size_t ldx, int mrows,
+                           const double *Fpack_all, int upper_tri, int c0, int c1)
+{
+    const int NB = GPMI_NB;
+    if (c1 - c0 <= NB) {
+        const int mr = (upper_tri && c1 < mrows) ? c1 : mrows;
+        hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)c0 * ldx, ldx, 0, mr, c1 - c0,
+                           Fpack_all + (size_t)(c0 / NB) * GPMI_FPACK);
+        return;
+    }
+    const int npan = (c1 - c0 + NB - 1) / NB;
+    const int cm = c0 + ((npan + 1) / 2) * NB;
+    trsm_right_rec(s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, c0, cm);
+    const int mr = (upper_tri && cm < mrows) ? cm : mrows;  // rows where X[:, c0:cm] is non-zero
+    const double *A = X + (size_t)c0 * ldx, *B = L + (size_t)cm + (size_t)c0 * ldl;
+    double *C = X + (size_t)cm * ldx;
+    if (upper_tri && (g_gemm_variant == 3 || g_gemm_variant == 0)) {
+        dim3 grid((c1 - cm + GT - 1) / GT, (mr + GT - 1) / GT);  // x: column tiles, y: row tiles (long K first)
+        hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 0x100, 0,
+                           FuseDiag{nullptr, nullptr, c0, 0, nullptr}, KSplit{});
+    } else {
+        launch_gemm_nt(s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 1);
+    }
+    trsm_right_rec(s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, cm, c1);
+}
+
 int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
                       int mrows, const double *Fpack_all, int upper_tri)
 {
@@ -1794,15 +1841,22 @@ int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X
     // [0, k + kb), which cuts the work to a third.
     hipStream_t s = c->stream;
     const int NB = GPMI_NB;
-    for (int k = 0; k < n; k += NB) {
-        const int kb = (n - k < NB) ? n - k : NB;
-        const double *Fp = Fpack_all + (size_t)(k / NB) * GPMI_FPACK;
-        const int mr = (upper_tri && k + kb < mrows) ? k + kb : mrows;
-        hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)k * ldx, ldx, 0, mr, kb, Fp);
-        const int r0 = k + kb;
-        if (r0 < n)
-            launch_gemm_nt(s, X + (size_t)k * ldx, ldx, L + (size_t)r0 + (size_t)k * ldl, ldl,
-                           X + (size_t)r0 * ldx, ldx, mr, n - r0, kb, 1);
+    // many right-hand rows: products with large K.  For a triangular X the recursion pays from
+    // N ~ 12k on (value + gradient at N = 16384: 88.9 -> 83.2 ms; N = 8192: 16.0 vs 16.5 ms, N = 4096:
+    // 4.5 vs 5.2 ms -- unequal tile lengths and more launches)
+    if (mrows >= 2 * GT && n > NB && (!upper_tri || n >= 12288)) {
+        trsm_right_rec(s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, 0, n);
+    } else {  // a few rows (triangular solve of vectors): one pass over L, panel by panel
+        for (int k = 0; k < n; k += NB) {
+            const int kb = (n - k < NB) ? n - k : NB;
+            const double *Fp = Fpack_all + (size_t)(k / NB) * GPMI_FPACK;
+            const int mr = (upper_tri && k + kb < mrows) ? k + kb : mrows;
+            hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)k * ldx, ldx, 0, mr, kb, Fp);
+            const int r0 = k + kb;
+            if (r0 < n)
+                launch_gemm_nt(s, X + (size_t)k * ldx, ldx, L + (size_t)r0 + (size_t)k * ldl, ldl,
+                               X + (size_t)r0 * ldx, ldx, mr, n - r0, kb, 1);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "trsm launch failed: %s", hipGetErrorString(e));
