@@ -145,3 +145,21 @@ def test_c5_derivative_joint(ctx, orc):
     assert np.all(info.cpu().numpy() == 0) and np.all(np.isfinite(o))
     # same scaling identity on the order-16384 joint matrix (jitter scales with c^2)
     assert abs(o[1, 0] - (o[0, 0] - 2 * n * math.log(c))) <= 1e-7 * abs(o[0, 0])
+
+
+def test_beyond_baseline_sizes_blockings_agree(ctx):
+    """N = 32768 (twice the largest BASELINE size) and a ragged N: no oracle at these sizes, so the
+    size-independent property is that two different blockings of the same factorisation (outer
+    blocks of 1024 and of 512 columns: different products, different summation orders) give the same
+    log marginal likelihood to 1e-10 relative -- far inside the 1e-8 bar."""
+    from gp_amd import synth
+    for n in (32768, 20001):
+        X, y = synth.synth(n, 3)
+        try:
+            ctx.set_option("nb_outer", 1024)
+            a = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+            ctx.set_option("nb_outer", 512)
+            b = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+        finally:
+            ctx.set_option("nb_outer", 0)
+        assert np.isfinite(a) and abs(a - b) <= 1e-10 * abs(a), (n, a, b)
