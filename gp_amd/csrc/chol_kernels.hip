@@ -506,10 +506,14 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(af[tn], bf[tm], acc[tn][tm]);
     };
-    auto compute = [&](auto mk, int st, int klim) {
+    // mid(): issued between the first fragment reads and the first MFMAs (the DMA of the next stage:
+    // its instructions then run under the LDS latency instead of in front of it)
+    auto compute = [&](auto mk, int st, int klim, auto &&mid) {
         double a0[4], b0[4], a1[4], b1[4];
         ldfrag(mk, st, 0, klim, a0, b0);
         ldfrag(mk, st, 1, klim, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
         __builtin_amdgcn_sched_barrier(0);
         if (dbg & 4) __builtin_amdgcn_s_setprio(3);  // probe: matrix work first when both waves of a SIMD can issue
         mm16(a0, b0);
@@ -526,12 +530,36 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
     };
 
     issue(0, 0);
+    if (K % GK == 0 && !(dbg & 16)) {
+        // Whole k-steps only (every launch of a factorisation whose order is a multiple of 16): no
+        // clamp, and the eight row addresses of a stage are one running per-lane pointer plus
+        // loop-invariant uniform offsets -- one VALU add per DMA instead of the ~12 scalar
+        // instructions (min, 64-bit multiply, ...) of the general form, which sat between the
+        // barrier and the first fragment reads of every k-step (~100 instructions per wave)
+        const double *gp = gsrc + (size_t)krow0 * gld;
 #pragma unroll 1
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (!(dbg & 2)) issue((kt + 1) & 1, (kt + 1) * GK);
-        compute(ic<0>{}, kt & 1, GK);
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            gp += (size_t)GK * gld;
+            compute(ic<0>{}, kt & 1, GK, [&]() {
+                if (!(dbg & 2)) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(gp + (size_t)q * gld),
+                            (__attribute__((address_space(3))) void *)&smem[(kt + 1) & 1][op][krow0 + q][0], 16, 0, 0);
+                }
+            });
+        }
+    } else {
+#pragma unroll 1
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!(dbg & 2)) issue((kt + 1) & 1, (kt + 1) * GK);
+            compute(ic<0>{}, kt & 1, GK, []() {});
+        }
     }
 
     // Last k-step peeled.  For a tile wholly inside the matrix the first half of the C tile
@@ -554,7 +582,7 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ch[tn][tm][i] = ld_c(cbase + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc, cnt);
     }
-    compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK);
+    compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK, []() {});
     if (dbg & 1) {
         double sacc = 0.0;
 #pragma unroll
