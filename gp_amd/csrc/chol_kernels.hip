@@ -515,7 +515,6 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
         __builtin_amdgcn_sched_barrier(0);
         mid();
         __builtin_amdgcn_sched_barrier(0);
-        if (dbg & 4) __builtin_amdgcn_s_setprio(3);  // probe: matrix work first when both waves of a SIMD can issue
         mm16(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         ldfrag(mk, st, 2, klim, a0, b0);
@@ -526,7 +525,6 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
         __builtin_amdgcn_sched_barrier(0);
         mm16(a0, b0);
         mm16(a1, b1);
-        if (dbg & 4) __builtin_amdgcn_s_setprio(0);
     };
 
     issue(0, 0);
