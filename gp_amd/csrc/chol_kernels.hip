@@ -540,6 +540,9 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             gp += (size_t)GK * gld;
+            // keep ONE running per-lane pointer (opaque to the optimiser, which otherwise turns the
+            // eight invariant offsets into eight running scalar pointers: 16 SALU per k-step)
+            asm volatile("" : "+v"(gp));
             compute(ic<0>{}, kt & 1, GK, [&]() {
                 if (!(dbg & 2)) {
 #pragma unroll
