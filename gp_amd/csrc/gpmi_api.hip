@@ -352,6 +352,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         g_syrk_persist = value;
         return 0;
     }
+    if (!strcmp(name, "se_nt")) {
+        extern int g_se_nt;
+        g_se_nt = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "ksplit")) {  // 0: off; 1: on; R > 1: on, split the tail round when it holds <= R tiles
         extern int g_ksplit, g_ksplit_max;
         g_ksplit = value != 0;

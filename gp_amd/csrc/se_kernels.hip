@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
             if (r + 1 == c) v1 = p.a2 + diag_add;
         }
         const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
-        store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
+        if (vec & 2) store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, true);
+        else store_pair<false>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
     }
 }
 
@@ -386,6 +387,8 @@ __global__ void k_hermite_mv_sum(const double *__restrict__ part, int n, int nch
 }
 }  // namespace
 
+int g_se_nt = 1;
+
 void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
                    const SeParams &p, double diag_add, int lower, double *dK, size_t ldk)
 {
@@ -394,7 +397,8 @@ void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double
     if (same) { dY = dX; ldy = ldx; }
     dim3 grid((n + TILE - 1) / TILE, (m + TILE - 1) / TILE);
     if (p.D <= GPMI_MAXD) grid = dim3((n + SE_TR - 1) / SE_TR, (m + SE_TC - 1) / SE_TC);  // k_se_cov<>
-    const int vec = vec_ok(dK, ldk);
+    extern int g_se_nt;
+    const int vec = vec_ok(dK, ldk) ? (g_se_nt ? 3 : 1) : 0;  // bit 1: non-temporal stores in k_se_cov<>
     switch (p.D) {
     case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
     case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
