@@ -336,33 +336,36 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, 
 // X L11^T = A21 by block forward substitution over the 8 block columns; each
 // wave carries its 16 rows through all steps in registers.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsm_panel(double *__restrict__ Acol, size_t lda, int row0,
-                                                    int M, int nb_act, const double *__restrict__ Fpack)
+// FULL: all 64 rows of the workgroup and all 128 columns exist -- unconditional, batched loads and
+// stores from one running column pointer (the guarded form predicates and branches per element)
+template <bool FULL>
+__device__ __forceinline__ void trsm_panel_body(const double *__restrict__ s_F, double *__restrict__ Acol, size_t lda,
+                                                int r, bool rok, int nb_act)
 {
-    __shared__ __attribute__((aligned(16))) double s_F[GPMI_FPACK];
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(Fpack);
-        double2 *dst = reinterpret_cast<double2 *>(s_F);
-#pragma unroll
-        for (int q = 0; q < GPMI_FPACK / 2 / 256; ++q) dst[threadIdx.x + 256 * q] = src[threadIdx.x + 256 * q];
-    }
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lr = lane & 15, lq = lane >> 4;
-    const int r = row0 + (blockIdx.x * 4 + w) * 16 + lr;
-    const int nblk = (nb_act + 15) >> 4;
-    const bool rok = r < M;
-
+    const int lq = lane >> 4;
+    const int nblk = FULL ? 8 : (nb_act + 15) >> 4;
     d4 T[8];
+    if constexpr (FULL) {
+        const double *p = Acol + (size_t)r + (size_t)lq * lda;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
+        for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = jb * 16 + lq + 4 * i;
-            T[jb][i] = (rok && col < nb_act) ? Acol[(size_t)r + (size_t)col * lda] : 0.0;
+            for (int i = 0; i < 4; ++i) {
+                T[jb][i] = *p;
+                p += 4 * lda;
+            }
+    } else {
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = jb * 16 + lq + 4 * i;
+                T[jb][i] = (rok && col < nb_act) ? Acol[(size_t)r + (size_t)col * lda] : 0.0;
+            }
         }
     }
-    __syncthreads();
+    __syncthreads();  // packed factors are in s_F
 
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
@@ -382,14 +385,45 @@ __global__ __launch_bounds__(256) void k_trsm_panel(double *__restrict__ Acol, s
         }
     }
 
+    if constexpr (FULL) {
+        double *p = Acol + (size_t)r + (size_t)lq * lda;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
+        for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = jb * 16 + lq + 4 * i;
-            if (rok && col < nb_act) Acol[(size_t)r + (size_t)col * lda] = T[jb][i];
+            for (int i = 0; i < 4; ++i) {
+                *p = T[jb][i];
+                p += 4 * lda;
+            }
+    } else {
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = jb * 16 + lq + 4 * i;
+                if (rok && col < nb_act) Acol[(size_t)r + (size_t)col * lda] = T[jb][i];
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_trsm_panel(double *__restrict__ Acol, size_t lda, int row0,
+                                                    int M, int nb_act, const double *__restrict__ Fpack)
+{
+    __shared__ __attribute__((aligned(16))) double s_F[GPMI_FPACK];
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(Fpack);
+        double2 *dst = reinterpret_cast<double2 *>(s_F);
+#pragma unroll
+        for (int q = 0; q < GPMI_FPACK / 2 / 256; ++q) dst[threadIdx.x + 256 * q] = src[threadIdx.x + 256 * q];
+    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rbase = row0 + blockIdx.x * 64;
+    const int r = rbase + w * 16 + (lane & 15);
+    if (nb_act == GPMI_NB && rbase + 64 <= M)  // workgroup-uniform
+        trsm_panel_body<true>(s_F, Acol, lda, r, true, nb_act);
+    else
+        trsm_panel_body<false>(s_F, Acol, lda, r, r < M, nb_act);
 }
 
 // ---------------------------------------------------------------------------
