@@ -561,7 +561,15 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
         mm16(a1, b1);
     };
 
-    issue(0, 0);
+    if (K % GK == 0 && !(dbg & 16)) {
+        const double *g0 = gsrc + (size_t)krow0 * gld;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)  // stage 0, same lean addressing as the loop
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g0 + (size_t)q * gld),
+                                             (__attribute__((address_space(3))) void *)&smem[0][op][krow0 + q][0], 16, 0, 0);
+    } else {
+        issue(0, 0);
+    }
     if (K % GK == 0 && !(dbg & 16)) {
         // Whole k-steps only (every launch of a factorisation whose order is a multiple of 16): no
         // clamp, and the eight row addresses of a stage are one running per-lane pointer plus
