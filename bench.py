@@ -9,10 +9,24 @@ blocked fp64 Cholesky -> forward solve -> log-det -> scalar.  N = 1 runs BASELIN
 config c3 (N=16384, D=3); with N > 1 GPUs every rank evaluates its own K hyper-parameter
 points on the same data (weak scaling, no data-path collective) and the per-point results
 are gathered once over RCCL at the end.  Prints ONE JSON line on rank 0.
+
+Launching: under torchrun (WORLD_SIZE set) this process is one rank.  A plain
+`python bench.py --gpus N` with N > 1 starts the N ranks itself -- child processes, one per
+GPU, created BEFORE this process imports torch or touches HIP (a process that has
+initialised the GPU is never forked or re-exec'ed) -- and exits with their status.  This
+replaces the reference's fork-per-draw (parallel::mclapply, pendulum_fit.R:261-268).
+
+The line also carries a `c4` sub-record: BASELINE config c4 (the 64-point rho x sigma grid at
+N=8192) sharded over the same ranks, its wall time, and the speed-up over ONE rank evaluating
+all 64 points in the same run (strong scaling), with the sharded results compared bit for bit.
 """
 import argparse
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +39,70 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 (matrix == vector); not in the
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--d", type=int, default=3)
+    ap.add_argument("--nb-outer", type=int, default=0)
+    ap.add_argument("--cpu-sample-n", type=int, default=8192)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
+                    help="c3 (default, the metric): N=16384 D=3 evaluations, weak scaling; c4: the 64-point "
+                         "rho x sigma grid at N=8192 sharded over the ranks (strong scaling); c5: derivative "
+                         "joint [y, y'] covariance, N=8192 (matrix order 16384)")
+    ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU (0 = auto)")
+    ap.add_argument("--lookahead", type=int, default=-1, choices=[-1, 0, 1],
+                    help="panel look-ahead inside one factorisation: 1 on, 0 off, -1 (default) library default")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / sharding / gather only (gloo, no GPU): the CPU test of the N>1 path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the c4 strong-scaling sub-record")
+    return ap.parse_args(argv)
+
+
+# ---- launcher (parent process: no torch, no HIP) ---------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(ngpus, argv):
+    """Start `ngpus` rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment) and wait for them.  The parent never initialises the GPU.  Returns the exit status:
+    0 only if every rank succeeded; when one rank fails the others are stopped (by pid)."""
+    assert "torch" not in sys.modules, "the launcher must run before torch is imported"
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GPMI_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                time.sleep(2.0)  # let the peers notice the broken rendezvous by themselves first
+                for q in live:
+                    if q.poll() is None:
+                        q.terminate()
+    return rc
+
+
+# ---- CPU legs -------------------------------------------------------------------------------------------
 def cpu_baseline(n_sample, D, cores=1):
     """Oracle (CPU restatement of the reference path, 1 thread like rstan/Eigen) timed on a
     bounded sample: one full evaluation at N = n_sample, scaled to the N=16384 metric by
@@ -64,26 +142,72 @@ def cpu_lapack(n_sample, D, threads):
     return dt, lm
 
 
+# ---- PMC summaries committed under profiles/ -----------------------------------------------------------
+def pmc_lookup(workload, order, kernel_substr):
+    """(hbm_bytes_per_launch, mfma_util, file) of a kernel from the newest committed rocprofv3 --pmc
+    summary taken over THIS workload at THIS matrix order (profiles/rNN_pmc_bench_<workload>_n<order>.json;
+    tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  (None, None, None) when no such summary exists -- a
+    figure measured at another size is never attributed to this run."""
+    pat = os.path.join(ROOT, "profiles", "r*_pmc_bench_%s_n%d.json" % (workload, order))
+    for path in sorted(glob.glob(pat), reverse=True):
+        try:
+            with open(path) as f:
+                for name, e in json.load(f).items():
+                    if kernel_substr in name:
+                        return e.get("hbm_bytes_per_launch"), e.get("mfma_util"), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None, None
+
+
+C4_N, C4_D, C4_G = 8192, 3, 64
+
+
+def c4_grid():
+    """8 x 8 (rho, sigma) grid, log-spaced; point g = 8 i_rho + i_sigma."""
+    R, S = np.meshgrid(np.geomspace(0.1, 1.0, 8), np.geomspace(0.05, 0.5, 8), indexing="ij")
+    return R.ravel(), S.ravel()
+
+
+def dry_run(args):
+    """The N>1 path without a GPU: same launcher, same rendezvous, same sharding (point g -> rank
+    g mod P) and the same all_gather as the c4 sub-record, with a closed-form stand-in for the
+    evaluation.  Used by tests/test_grid_gloo.py."""
+    import torch.distributed as dist
+    from gp_amd.grid import logml_grid_sharded
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rho, sig = c4_grid()
+
+    def fake(X, y, alpha, rho, sigma, jitter):
+        out = np.stack([np.sin(7.0 * rho) - sigma, np.log(rho), sigma * sigma], axis=1)
+        return out, np.zeros(len(rho), dtype=np.int32)
+
+    res, info = logml_grid_sharded(None, None, np.ones(C4_G), rho, sig, 0.0, evaluate=fake)
+    want, _ = fake(None, None, None, rho, sig, 0.0)
+    ok = bool(np.array_equal(res, want) and np.all(info == 0))
+    n_seen = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": n_seen, "gpus_arg": args.gpus, "grid_points": C4_G,
+                          "results_ok": ok, "launched_by_bench": bool(os.environ.get("GPMI_BENCH_LAUNCHED"))}))
+        sys.stdout.flush()
+    return 0 if ok else 1
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--d", type=int, default=3)
-    ap.add_argument("--nb-outer", type=int, default=0)
-    ap.add_argument("--cpu-sample-n", type=int, default=8192)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5"],
-                    help="c3 (default, the metric): N=16384 D=3 evaluations, weak scaling; c4: the 64-point "
-                         "rho x sigma grid at N=8192 sharded over the ranks (strong scaling); c5: derivative "
-                         "joint [y, y'] covariance, N=8192 (matrix order 16384)")
-    ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU in c4 (0 = auto)")
-    ap.add_argument("--lookahead", type=int, default=-1, choices=[-1, 0, 1],
-                    help="panel look-ahead inside one factorisation: 1 on; 0 / -1 (default) off")
-    ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     import torch
     import torch.distributed as dist
@@ -94,20 +218,26 @@ def main():
     distributed = world > 1
     if args.rehearse:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d needs cuda:%d but only %d device(s) are visible "
+                         "(use --rehearse to run every rank on cuda:0)\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()   # what the collective layer actually sees
 
     import gp_amd
     ctx = gp_amd.Context(local_rank)
     n, D = args.n, args.d
     if args.workload == "c4":
-        n = 8192
+        n = C4_N
     elif args.workload == "c5":
         n, D = 8192, 1
     if args.nb_outer:
@@ -123,7 +253,9 @@ def main():
     dX = torch.from_numpy(np.ascontiguousarray(X.T)).to(dev)   # (D, n) row-major == n x D column-major
     dy = torch.from_numpy(y).to(dev)
     steps, warm = args.steps, args.warmup
-    stream = torch.cuda.current_stream(dev)
+    # Everything below -- the library's launches, the copy of the results and the gather -- is enqueued
+    # on ONE explicit torch stream, so the collective is ordered behind the evaluations it sends
+    stream = torch.cuda.Stream(dev)
     ctx.set_stream(stream.cuda_stream)
     cdev = torch.device("cpu") if args.rehearse else dev  # gloo rehearsal: collectives on host tensors
 
@@ -134,13 +266,13 @@ def main():
         rho = 0.3 * (1.0 + 0.01 * ((np.arange(npts) * world + rank) % 16))
         sig = 0.1 * np.ones(npts)
     elif args.workload == "c4":
-        # 8 x 8 (rho, sigma) grid, log-spaced; point g -> rank g mod world
-        R, S = np.meshgrid(np.geomspace(0.1, 1.0, 8), np.geomspace(0.05, 0.5, 8), indexing="ij")
-        mine = np.arange(rank, 64, world)
+        # point g -> rank g mod world
+        R, S = c4_grid()
+        mine = np.arange(rank, C4_G, world)
         per_step = mine.size
         npts = per_step * (steps + warm)
-        rho = np.tile(R.ravel()[mine], steps + warm)
-        sig = np.tile(S.ravel()[mine], steps + warm)
+        rho = np.tile(R[mine], steps + warm)
+        sig = np.tile(S[mine], steps + warm)
     else:
         per_step = 1
         npts = steps + warm
@@ -152,9 +284,8 @@ def main():
     dout = torch.zeros((npts, 3), dtype=torch.float64, device=dev)
     dinfo = torch.zeros(npts, dtype=torch.int32, device=dev)
 
-    if args.grid_lanes:
-        ctx.set_option("grid_lanes", args.grid_lanes)
-    ctx.set_option("lookahead", args.lookahead)
+    if args.lookahead >= 0:
+        ctx.set_option("lookahead", args.lookahead)
 
     def run_points(lo, hi):
         """Evaluate points lo..hi-1 of this rank.  c3 / c4 go through the grid entry point, which
@@ -167,30 +298,32 @@ def main():
             ctx.logml_grid_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), np.ones(hi - lo), rho[lo:hi], sig[lo:hi], 0.0,
                                dout[lo].data_ptr(), dinfo[lo:].data_ptr())
 
-    if warm:
-        run_points(0, warm * per_step)
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run_points(warm * per_step, (warm + steps) * per_step)  # exactly `steps` steps
-    if distributed:
-        # the path's only collective: gather the per-point results (3 doubles per point)
-        send = dout.to(cdev)
-        gathered = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(gathered, send)
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        if warm:
+            run_points(0, warm * per_step)
+        barrier()
+        t0 = time.perf_counter()
+        run_points(warm * per_step, (warm + steps) * per_step)  # exactly `steps` steps
+        if distributed:
+            # the path's only collective: gather the per-point results (3 doubles per point); same
+            # stream as the evaluations, so it reads them only after the lanes have joined
+            send = dout.to(cdev)
+            gathered = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(gathered, send)
+        barrier()
+        elapsed = time.perf_counter() - t0
 
     # Roofline pass (same run, rank 0 only, after the timed region): the same evaluations one at
-    # a time with HIP-event pairs around every covariance-build and trailing-update launch on
-    # the launch stream.  Done separately because concurrent lanes overlap launches, which makes
-    # per-launch durations meaningless inside the throughput region.
-    kt = {"syrk": (0, 0.0, 0.0), "build": (0, 0.0, 0.0)}
+    # a time with HIP-event pairs around every covariance-build, trailing-update and panel-phase
+    # launch group on the launch stream.  Done separately because concurrent lanes overlap launches,
+    # which makes per-launch durations meaningless inside the throughput region.
+    kt = {"syrk": (0, 0.0, 0.0), "build": (0, 0.0, 0.0), "panel": (0, 0.0, 0.0)}
     seq_ms = None
     if rank == 0:
         ctx.set_option("grid_lanes", 1)
@@ -198,16 +331,27 @@ def main():
         ctx.set_option("kernel_timing", 1)
         ctx.kernel_timing(reset=True)
         nprof = min(steps * per_step, 4)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        lo = warm * per_step
-        for p in range(lo, lo + nprof):
-            run_points(p, p + 1)
-        torch.cuda.synchronize(dev)
-        seq_ms = 1e3 * (time.perf_counter() - t1) / nprof
+        with torch.cuda.stream(stream):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            lo = warm * per_step
+            for p in range(lo, lo + nprof):
+                run_points(p, p + 1)
+            torch.cuda.synchronize(dev)
+            seq_inst_ms = 1e3 * (time.perf_counter() - t1) / nprof
         kt = ctx.kernel_timing(reset=True)
         ctx.set_option("kernel_timing", 0)
+        # ... and the library's default one-at-a-time path (what a NUTS / optimiser loop sees: one
+        # evaluation per step), without instrumentation
         ctx.set_option("lookahead", args.lookahead)
+        with torch.cuda.stream(stream):
+            run_points(lo, lo + 1)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for p in range(lo, lo + nprof):
+                run_points(p, p + 1)
+            torch.cuda.synchronize(dev)
+            seq_ms = 1e3 * (time.perf_counter() - t1) / nprof
         ctx.set_option("grid_lanes", args.grid_lanes)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -218,28 +362,84 @@ def main():
     info = dinfo.cpu().numpy()
     ok = bool(np.all(info == 0) and np.all(np.isfinite(res[:, 0])))
 
-    def pmc_traffic(kernel_substr):
-        """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes over this same
-        command (tools/pmc_bench.sh; FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as
-        MI355X_MICROARCH.md prescribes for gfx950).  None when no PMC summary is committed."""
-        path = os.path.join(ROOT, "profiles", "r01_pmc_bench_%s.json" % args.workload)
-        try:
-            with open(path) as f:
-                for name, e in json.load(f).items():
-                    if kernel_substr in name and "hbm_bytes_per_launch" in e:
-                        return e["hbm_bytes_per_launch"], e.get("mfma_util"), os.path.relpath(path, ROOT)
-        except (OSError, ValueError):
-            pass
-        return None, None, None
+    # ---- c4 sub-record: the 64-point grid at N=8192 over the same ranks (strong scaling) --------------
+    c4 = None
+    if args.workload == "c3" and not args.no_c4:
+        X4, y4 = synth(C4_N, C4_D)
+        dX4 = torch.from_numpy(np.ascontiguousarray(X4.T)).to(dev)
+        dy4 = torch.from_numpy(y4).to(dev)
+        R4, S4 = c4_grid()
+        mine = np.arange(rank, C4_G, world)
+        per = (C4_G + world - 1) // world
+        loc = torch.full((per, 3), float("nan"), dtype=torch.float64, device=dev)
+        linfo = torch.zeros(per, dtype=torch.int32, device=dev)
+        full = torch.zeros((C4_G, 3), dtype=torch.float64, device=dev)
+        finfo = torch.zeros(C4_G, dtype=torch.int32, device=dev)
+
+        def grid_points(idx, o, i):
+            ctx.logml_grid_dev(dX4.data_ptr(), C4_N, C4_N, C4_D, dy4.data_ptr(), np.ones(idx.size), R4[idx], S4[idx], 0.0,
+                               o.data_ptr(), i.data_ptr())
+
+        with torch.cuda.stream(stream):
+            grid_points(mine, loc, linfo)  # warm-up
+            barrier()
+            t0 = time.perf_counter()
+            grid_points(mine, loc, linfo)
+            if distributed:
+                send = loc.to(cdev)
+                parts = [torch.empty_like(send) for _ in range(world)]
+                dist.all_gather(parts, send)
+            barrier()
+            tN = time.perf_counter() - t0
+            # the same run's ONE-rank figure: rank 0 evaluates all 64 points, the others wait
+            t1r = tN
+            if distributed:
+                if rank == 0:
+                    allp = np.arange(C4_G)
+                    grid_points(allp, full, finfo)
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    grid_points(allp, full, finfo)
+                    torch.cuda.synchronize(dev)
+                    t1r = time.perf_counter() - t0
+                barrier()
+        tt = torch.tensor([tN], dtype=torch.float64, device=cdev)
+        if distributed:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tN = float(tt.item())
+        if rank == 0:
+            if distributed:
+                got = np.full((C4_G, 3), np.nan)
+                recv = torch.stack(parts).cpu().numpy()
+                for r in range(world):
+                    idx = np.arange(r, C4_G, world)
+                    got[idx] = recv[r, : idx.size]
+                ref4 = full.cpu().numpy()
+                same = bool(np.array_equal(got, ref4))
+            else:
+                got = loc.cpu().numpy()
+                same = True
+            c4 = {"workload": "c4: 64-point (rho x sigma) grid at N=%d, D=%d, point g -> rank g mod %d, one all_gather"
+                              % (C4_N, C4_D, world),
+                  "grid_points": C4_G, "n_gpus": world, "wall_s": tN, "evals_per_s": C4_G / tN,
+                  "wall_s_one_rank_same_run": t1r, "speedup_vs_one_rank": t1r / tN,
+                  "sharded_results_bit_identical_to_one_rank": same,
+                  "results_ok": bool(np.all(np.isfinite(got[:, 0]))),
+                  "argmax_point": int(np.nanargmax(got[:, 0])), "logml_max": float(np.nanmax(got[:, 0]))}
 
     if rank == 0:
-        evals = steps * (64 if args.workload == "c4" else world * per_step)
+        evals = steps * (C4_G if args.workload == "c4" else world * per_step)
         value = evals / elapsed
         order = 2 * n if args.workload == "c5" else n
         syrk_n, syrk_ms, syrk_flops = kt["syrk"]
         build_n, build_ms, build_bytes = kt["build"]
+        pan_n, pan_ms, pan_flops = kt["panel"]
         ach = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        pach = pan_flops / (pan_ms * 1e-3) / 1e12 if pan_ms > 0 else 0.0
         chol_flops = order ** 3 / 3.0
+        nbo_auto = (lambda nf: 1024 if nf >= 12288 else 512 if nf >= 6144 else 256)(order)
+        build_kernel = "k_joint_cov" if args.workload == "c5" else "k_se_cov<%d>" % D
+        syrk_traffic, syrk_util, syrk_src = pmc_lookup(args.workload, order, "k_gemm_nt<1>")
         line = {
             "metric": {"c3": "gp_logml_evals_per_sec_N%d_D%d" % (n, D),
                        "c4": "gp_logml_grid64_evals_per_sec_N%d_D%d" % (n, D),
@@ -262,11 +462,15 @@ def main():
                       "whole grid" % (n, D),
                 "c5": "c5: derivative joint [y, y'] covariance, N=%d (matrix order %d), build + fp64 Cholesky "
                       "+ solve + log-det" % (n, 2 * n)}[args.workload],
-                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1, "nb_outer": args.nb_outer or "auto(%d)" % (lambda nf: 1024 if nf >= 12288 else 512 if nf >= 6144 else 256)(2 * n if args.workload == "c5" else n),
+                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1,
+                       "nb_outer": args.nb_outer or "auto(%d)" % nbo_auto,
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
+            "launched_by": "bench.py launcher" if os.environ.get("GPMI_BENCH_LAUNCHED") else
+                           ("torchrun / external" if distributed else "single process"),
             "grid_lanes": args.grid_lanes or "auto(4)",
             "ms_per_eval_sequential": seq_ms,
+            "ms_per_eval_sequential_instrumented": seq_inst_ms,
             "logml_first": float(res[warm * per_step, 0]),
             "cholesky_tflops_per_gpu_whole_eval": chol_flops * evals / world / elapsed / 1e12,
             "roofline": {
@@ -278,27 +482,43 @@ def main():
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic("k_gemm_nt<1>")[0],
+                "traffic": syrk_traffic,
                 "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes)",
-                "traffic_source": pmc_traffic("k_gemm_nt<1>")[2],
-                "mfma_util_pmc": pmc_traffic("k_gemm_nt<1>")[1],
+                "traffic_source": syrk_src,
+                "mfma_util_pmc": syrk_util,
                 "launches": int(syrk_n),
                 "avg_launch_ms": syrk_ms / max(syrk_n, 1),
                 "flops_per_launch_avg": syrk_flops / max(syrk_n, 1),
             },
+            "roofline_panel": {
+                "kernel": "panel phase of one outer block: k_potrf_diag + k_trsm_panel + k_gemm_nt<0> (in-block "
+                          "products with the fused diagonal blocks); latency chain, 128 sequential pivot blocks",
+                "bound": "mfma",
+                "achieved": pach,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": pach / FP64_PEAK_TFLOPS,
+                "outer_blocks": int(pan_n),
+                "ms_per_eval": pan_ms / max(nprof, 1),
+                "mfma_util_pmc_gemm_nt0": pmc_lookup(args.workload, order, "k_gemm_nt<0>")[1],
+                "mfma_util_pmc_trsm_panel": pmc_lookup(args.workload, order, "k_trsm_panel")[1],
+                "traffic_gemm_nt0": pmc_lookup(args.workload, order, "k_gemm_nt<0>")[0],
+            },
             "roofline_build": {
                 "kernel": "k_joint_cov (lower-triangular joint [y, y'] covariance build)" if args.workload == "c5"
-                else "k_se_cov<3> (lower-triangular SE covariance build)",
+                else "%s (lower-triangular SE covariance build)" % build_kernel,
                 "bound": "hbm",
                 "achieved": build_bytes / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (build_bytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if build_ms > 0 else 0.0,
-                "traffic": pmc_traffic("k_joint_cov" if args.workload == "c5" else "k_se_cov<3>")[0],
+                "traffic": pmc_lookup(args.workload, order, build_kernel)[0],
                 "algorithmic_bytes_per_launch": build_bytes / max(build_n, 1),
                 "avg_launch_ms": build_ms / max(build_n, 1),
             },
         }
+        if c4 is not None:
+            line["c4"] = c4
         if world == 1:
             # one large stand-alone launch of the same kernel (m = 14336, K = 1024: 12.4 rounds of tiles),
             # HIP events around 6 back-to-back launches: the per-launch rate without the small
@@ -311,6 +531,14 @@ def main():
                                                          "frac": tf_l / FP64_PEAK_TFLOPS}
             except Exception as e:  # diagnostic only
                 line["roofline"]["standalone_launch"] = {"error": repr(e)}
+        if world == 1 and args.workload == "c3":
+            # the host-buffer entry point `.Call` binds (gpmi_logml): X, y over PCIe, 3 doubles back,
+            # blocking -- the PCIe-inclusive time of one evaluation, never `value`
+            ctx.set_stream(None)
+            ctx.logml(X, y, 1.0, [0.3], 0.1)
+            t1 = time.perf_counter()
+            ctx.logml(X, y, 1.0, [0.3], 0.1)
+            line["ms_per_eval_host_buffer_abi"] = 1e3 * (time.perf_counter() - t1)
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             ns = args.cpu_sample_n
             dt, lm_cpu = cpu_baseline(ns, D)
@@ -330,19 +558,24 @@ def main():
                 "sample_rel_err_gpu_vs_cpu": abs(lm_gpu - lm_cpu) / abs(lm_cpu),
                 "host_cores_available": os.cpu_count(),
             }
-            try:
-                thr = min(16, os.cpu_count() or 1)   # the CPU share of a one-GPU box
-                dt2, lm2 = cpu_lapack(ns, D, thr)
-                line["cpu_baseline"]["lapack_multicore"] = {
-                    "value": 1.0 / (dt2 * scale), "unit": "evals/s", "cores": thr,
-                    "sample": "numpy + LAPACK dpotrf/dtrtrs (scipy, OpenBLAS) at N=%d (%.2f s), scaled by "
-                              "(N/Ns)^3; upper bound for a CPU build, not the reference's path" % (ns, dt2),
-                    "sample_rel_err_vs_oracle": abs(lm2 - lm_cpu) / abs(lm_cpu)}
-            except Exception as e:  # optional leg: never fails the bench line
-                line["cpu_baseline"]["lapack_multicore"] = {"error": repr(e)}
+            # best-effort legs: LAPACK on the CPU share of a one-GPU box (16 threads) and on ALL host cores
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            line["cpu_baseline"]["host_cores_usable"] = usable
+            for key, thr in (("lapack_16_threads", min(16, usable)), ("lapack_all_cores", usable)):
+                try:
+                    cpu_lapack(1024, D, thr)  # thread-pool warm-up
+                    dt2, lm2 = cpu_lapack(ns, D, thr)
+                    line["cpu_baseline"][key] = {
+                        "value": 1.0 / (dt2 * scale), "unit": "evals/s", "cores": thr,
+                        "sample": "numpy + LAPACK dpotrf/dtrtrs (scipy, OpenBLAS) at N=%d (%.2f s), scaled by "
+                                  "(N/Ns)^3; upper bound for a CPU build, not the reference's path" % (ns, dt2),
+                        "sample_rel_err_vs_oracle": abs(lm2 - lm_cpu) / abs(lm_cpu)}
+                except Exception as e:  # optional leg: never fails the bench line
+                    line["cpu_baseline"][key] = {"error": repr(e)}
         print(json.dumps(line))
         sys.stdout.flush()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

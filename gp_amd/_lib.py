@@ -17,7 +17,7 @@ FULL, LOWER, COMPAT_RR = 0, 1, 2
 # every symbol include/gpmi.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
     "gpmi_version", "gpmi_last_error", "gpmi_device_count", "gpmi_create", "gpmi_destroy",
-    "gpmi_set_stream", "gpmi_sync", "gpmi_reserve", "gpmi_set_option",
+    "gpmi_set_stream", "gpmi_reset_stream", "gpmi_sync", "gpmi_reserve", "gpmi_set_option",
     "gpmi_se_cov", "gpmi_se_cov_dev", "gpmi_deriv_cov", "gpmi_deriv_cov_dev", "gpmi_deriv_elem",
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
@@ -152,7 +152,12 @@ class Context:
 
     # ---- plumbing -----------------------------------------------------------
     def set_stream(self, stream_handle):
-        _chk(self._lib.gpmi_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+        """Run on the caller's hipStream_t (handle 0 = the legacy null stream, torch's default
+        stream); None goes back to the context's own stream."""
+        if stream_handle is None:
+            _chk(self._lib.gpmi_reset_stream(self._h))
+        else:
+            _chk(self._lib.gpmi_set_stream(self._h, C.c_void_p(int(stream_handle))))
 
     def sync(self):
         _chk(self._lib.gpmi_sync(self._h))
@@ -429,10 +434,12 @@ _default = {}
 
 
 def default_context(device=None):
-    """Process-wide lazily created context (one per device); re-created after fork."""
+    """Process-wide lazily created context (one per device).  In a forked child of a process that
+    already used the GPU the library answers GPMI_EFORK (HIP cannot be re-initialised there): the
+    parent's context is never handed out and none is created behind the caller's back."""
     if device is None:
         device = int(os.environ.get("GPMI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     key = (os.getpid(), device)
     if key not in _default:
-        _default[key] = Context(device)
+        _default[key] = Context(device)  # raises GpmiError(-5) in a forked child of a GPU process
     return _default[key]

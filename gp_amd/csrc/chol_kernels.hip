@@ -1803,7 +1803,10 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             const int ke = (ko + nbo < nfac) ? ko + nbo : nfac;
             kt_begin(c, 2, s);
             panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, nbo, 0, M, true, s, diag_done);
-            kt_end(c, 2, 0.0, s);
+            {   // algorithmic flops of the panel phase: diagonal block w^3/3 + rows below (m - w) w^2
+                const double w = (double)(ke - ko), m = (double)(M - ko);
+                kt_end(c, 2, w * w * (m - w) + w * w * w / 3.0, s);
+            }
             diag_done = false;
             if (ke >= M || ke >= ncol) continue;
             const double mt = (double)(ncol - ke), extra = (double)(M - ncol);

@@ -27,9 +27,28 @@ int gpmi_fail(int code, const char *fmt, ...)
 extern "C" const char *gpmi_last_error(void) { return g_err; }
 extern "C" int gpmi_version(void) { return GPMI_VERSION; }
 
+// HIP / HSA state does not survive fork() and cannot be re-initialised in the child of a process
+// that already initialised it (parallel::mclapply, pendulum_fit.R:268): the first call that touches
+// the runtime records the pid, every later one from another pid answers GPMI_EFORK instead of
+// reaching into the stale runtime.
+static int g_hip_pid = 0;
+static int fork_guard(void)
+{
+    const int pid = (int)getpid();
+    if (g_hip_pid == 0) g_hip_pid = pid;
+    if (g_hip_pid != pid)
+        return gpmi_fail(GPMI_EFORK, "libgpmi initialised the GPU in process %d; this is forked child %d, where HIP cannot be "
+                                     "re-initialised: start workers as fresh processes or fork before the first gpmi call",
+                         g_hip_pid, pid);
+    return 0;
+}
+
 extern "C" int gpmi_device_count(int *count)
 {
     if (!count) return gpmi_fail(GPMI_EARG, "count is NULL");
+    *count = 0;
+    int rc = fork_guard();
+    if (rc) return rc;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) {
@@ -212,6 +231,8 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
 {
     if (!out) return gpmi_fail(GPMI_EARG, "ctx out pointer is NULL");
     *out = nullptr;
+    int rc_fork = fork_guard();
+    if (rc_fork) return rc_fork;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return gpmi_fail(GPMI_ENODEV, "no HIP device visible (libgpmi has no CPU fallback)");
@@ -299,7 +320,16 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
 extern "C" int gpmi_set_stream(gpmi_ctx *c, void *hip_stream)
 {
     ENTER(c);
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    // handle 0 is HIP's legacy null stream (torch's default stream has cuda_stream == 0): work is
+    // then ordered with everything else the caller enqueues there
+    c->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+extern "C" int gpmi_reset_stream(gpmi_ctx *c)
+{
+    ENTER(c);
+    c->stream = c->own_stream;
     return 0;
 }
 

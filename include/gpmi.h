@@ -20,9 +20,12 @@
  *    binds.  `_dev` entry points take device pointers (e.g. torch tensors'
  *    data_ptr()), enqueue on the context's stream and do NOT synchronise.
  *  - A gpmi_ctx owns its device workspace and stream; it is bound to one GPU
- *    and to the creating process (HIP state does not survive fork(): calls
- *    from a forked child -- e.g. parallel::mclapply at pendulum_fit.R:268 --
- *    return GPMI_EFORK; create a context per process).
+ *    and to the creating process.  HIP state does not survive fork() and cannot
+ *    be re-initialised in the child: once the library has touched the GPU in a
+ *    process, EVERY call from a forked child of it -- e.g. parallel::mclapply
+ *    at pendulum_fit.R:268 --, gpmi_create and gpmi_device_count included,
+ *    returns GPMI_EFORK.  Workers must be fresh processes (or fork before the
+ *    first gpmi call); prefer the grid API to fork-per-draw.
  *  - There is no CPU fallback anywhere in the library: without a HIP device
  *    gpmi_create fails with GPMI_ENODEV.
  */
@@ -46,7 +49,7 @@ enum {
     GPMI_EHIP = -2,   /* HIP runtime error                         */
     GPMI_ENOMEM = -3, /* device allocation failed                  */
     GPMI_ENODEV = -4, /* no usable gfx950 device                   */
-    GPMI_EFORK = -5   /* context used from a forked child process  */
+    GPMI_EFORK = -5   /* called from a forked child of a GPU process */
 };
 
 /* derivative-kernel selector: derivative_kernels.R:39-73 (Q value, R first,
@@ -69,8 +72,11 @@ const char *gpmi_last_error(void);
 int gpmi_device_count(int *count);
 int gpmi_create(gpmi_ctx **ctx, int device);
 int gpmi_destroy(gpmi_ctx *ctx);
-/* run on a caller-owned hipStream_t (NULL restores the context's own stream) */
+/* run on a caller-owned hipStream_t; NULL (handle 0) is HIP's legacy null stream -- what
+ * torch's default stream is -- so `_dev` calls are ordered with the caller's other work there */
 int gpmi_set_stream(gpmi_ctx *ctx, void *hip_stream);
+/* back to the context's own (non-blocking) stream */
+int gpmi_reset_stream(gpmi_ctx *ctx);
 int gpmi_sync(gpmi_ctx *ctx);
 /* pre-size the factorisation workspace for matrices of order <= n_max */
 int gpmi_reserve(gpmi_ctx *ctx, int n_max);

@@ -10,8 +10,10 @@
  *   - arguments of .Call are shared, never modified (copy-on-modify semantics);
  *   - outputs are allocated with Rf_allocMatrix / Rf_allocVector under PROTECT;
  *   - the ABI returns a status; all C resources are released BEFORE Rf_error (a longjmp);
- *   - one lazily created context per process (HIP does not survive fork():
- *     parallel::mclapply children get GPMI_EFORK -> re-create after a PID change).
+ *   - one lazily created context per process.  HIP does not survive fork() and cannot be
+ *     re-initialised in the child: parallel::mclapply children of an R session that already
+ *     used the GPU get GPMI_EFORK from every call (gpmi_create included) and the shim reports
+ *     it as an R error -- use mc.cores = 1, PSOCK workers, or the grid entry point.
  */
 #include <string.h>
 #include <R.h>
@@ -21,15 +23,13 @@
 #include "gpmi.h"
 
 static gpmi_ctx *g_ctx = NULL;
-static int g_pid = 0;
 
 static gpmi_ctx *ctx(void)
 {
-    if (g_ctx && g_pid != (int)getpid()) g_ctx = NULL; /* forked child: parent's handle is unusable */
+    /* in a forked child the parent's handle answers GPMI_EFORK by itself; it is not replaced */
     if (!g_ctx) {
         int rc = gpmi_create(&g_ctx, 0);
         if (rc) Rf_error("libgpmi: %s", gpmi_last_error());
-        g_pid = (int)getpid();
     }
     return g_ctx;
 }

@@ -90,15 +90,22 @@ def test_context_is_rejected_in_forked_child(ctx):
     pid = os.fork()
     if pid == 0:
         try:
+            import ctypes
             rc = h.gpmi_sync(ctx._h)
-            os.write(w, str(rc).encode())
+            # a NEW context cannot be made in the child either (HIP cannot be re-initialised there):
+            # gpmi_create and gpmi_device_count must answer GPMI_EFORK without touching the runtime
+            h2 = ctypes.c_void_p()
+            rc2 = h.gpmi_create(ctypes.byref(h2), 0)
+            cnt = ctypes.c_int(-1)
+            rc3 = h.gpmi_device_count(ctypes.byref(cnt))
+            os.write(w, ("%d %d %d %d %d" % (rc, rc2, rc3, cnt.value, int(bool(h2.value)))).encode())
         finally:
             os._exit(0)
     os.close(w)
     os.waitpid(pid, 0)
-    rc = int(os.read(r, 16).decode() or "0")
+    got = [int(v) for v in (os.read(r, 64).decode() or "0 0 0 0 0").split()]
     os.close(r)
-    assert rc == -5
+    assert got == [-5, -5, -5, 0, 0], got
     assert math.isfinite(ctx.logml(np.arange(5.0), np.ones(5), 1.0, [1.0], 0.5)[0])  # parent unaffected
 
 

@@ -302,6 +302,28 @@ def test_device_pointer_api_with_torch(ctx, orc):
         ctx.set_stream(None)
     want = orc.logml(X, y, 1.0, 0.3, 0.1)
     assert int(info.item()) == 0 and abs(out[0].item() - want[0]) <= LOGML_RTOL * abs(want[0])
+    # torch's DEFAULT stream has handle 0 (HIP's legacy null stream): a torch op issued right after a
+    # _dev call must see its result without any synchronisation in between -- single evaluation and
+    # the multi-lane grid (lanes fork from / join into the caller's stream)
+    cur = torch.cuda.current_stream(dev)
+    assert cur.cuda_stream == 0
+    ctx.set_stream(cur.cuda_stream)
+    try:
+        n2 = 3000
+        X2, y2 = orc.synth(n2, 3)
+        dX2 = torch.from_numpy(np.asfortranarray(X2).T.copy()).to(dev); dy2 = torch.from_numpy(y2).to(dev)
+        o1 = torch.zeros(3, dtype=torch.float64, device=dev)
+        ctx.logml_dev(dX2.data_ptr(), n2, n2, 3, dy2.data_ptr(), 1.0, [0.3], 0.1, 0.0, o1.data_ptr(), info.data_ptr())
+        seen1 = o1.clone()                       # enqueued on the null stream right behind the evaluation
+        og = torch.zeros((6, 3), dtype=torch.float64, device=dev); ig = torch.zeros(6, dtype=torch.int32, device=dev)
+        ctx.logml_grid_dev(dX2.data_ptr(), n2, n2, 3, dy2.data_ptr(), np.ones(6), np.full(6, 0.3), np.full(6, 0.1), 0.0,
+                           og.data_ptr(), ig.data_ptr())
+        seeng = og.clone()
+        torch.cuda.synchronize(dev)
+    finally:
+        ctx.set_stream(None)
+    ref2 = ctx.logml(X2, y2, 1.0, [0.3], 0.1)[0]
+    assert seen1[0].item() == ref2 and bool((seeng[:, 0] == ref2).all().item())
     # potrf_dev in place on a torch matrix
     A = orc.cov_exp_quad(X, 1.0, 0.3) + 0.01 * np.eye(500)
     dA = torch.from_numpy(np.ascontiguousarray(A.T)).to(dev)  # symmetric: either order

@@ -59,3 +59,25 @@ def test_grid_sharded_two_ranks():
         np.testing.assert_array_equal(info, winfo)
         np.testing.assert_allclose(res, want, rtol=0, atol=0, equal_nan=True)
     assert winfo[4] > 0 and np.isnan(want[4, 0])
+
+
+def test_bench_launcher_spawns_ranks_and_gathers():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts the two ranks itself (child processes made
+    before anything touches a GPU), they rendezvous over gloo, shard the 64-point c4 grid g -> g mod 2 and
+    all_gather it -- the bench's own N>1 path, with a closed-form stand-in for the evaluation (--dry-run)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["launched_by_bench"] and rec["results_ok"] and rec["grid_points"] == 64
+    # a failing rank fails the launcher (no silent success)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--workload", "nope"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0
