@@ -519,18 +519,6 @@ def main():
         }
         if c4 is not None:
             line["c4"] = c4
-        if world == 1:
-            # one large stand-alone launch of the same kernel (m = 14336, K = 1024: 12.4 rounds of tiles),
-            # HIP events around 6 back-to-back launches: the per-launch rate without the small
-            # trailing matrices that pull the whole-factorisation average down
-            try:
-                ctx.set_stream(None)
-                ctx.probe_syrk(14336, 1024, 2)
-                ms_l, tf_l = ctx.probe_syrk(14336, 1024, 6)
-                line["roofline"]["standalone_launch"] = {"m": 14336, "k": 1024, "ms": ms_l, "achieved": tf_l,
-                                                         "frac": tf_l / FP64_PEAK_TFLOPS}
-            except Exception as e:  # diagnostic only
-                line["roofline"]["standalone_launch"] = {"error": repr(e)}
         if world == 1 and args.workload == "c3":
             # the host-buffer entry point `.Call` binds (gpmi_logml): X, y over PCIe, 3 doubles back,
             # blocking -- the PCIe-inclusive time of one evaluation, never `value`

@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["se_kernels.hip", "chol_kernels.hip", "gpmi_api.hip"]
 LIB = os.path.join(CSRC, "libgpmi.so")
+PROBES_LIB = os.path.join(CSRC, "libgpmi_probes.so")  # -DGPMI_PROBES: tools/ only, never loaded by the product
 
 
 def hipcc():
@@ -17,10 +18,10 @@ def hipcc():
     raise RuntimeError("hipcc not found; libgpmi cannot be built (there is no CPU fallback)")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [
         os.path.join(CSRC, "gpmi_internal.h"),
         os.path.join(CSRC, "factor16.h"),
@@ -29,16 +30,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=False, probes=False):
+    lib = PROBES_LIB if probes else LIB
+    if not force and not needs_build(lib):
+        return lib
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++20", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-fvisibility=hidden"] + (["-DGPMI_PROBES"] if probes else []) + ["-o", lib] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, probes="--probes" in sys.argv[1:]))

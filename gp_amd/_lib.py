@@ -10,6 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgpmi.so")
+PROBES_LIB_PATH = os.path.join(_HERE, "csrc", "libgpmi_probes.so")
 
 KINDS = ("QQ", "QR", "RQ", "RR", "QT", "TQ", "RT", "TR", "TT")
 FULL, LOWER, COMPAT_RR = 0, 1, 2
@@ -25,8 +26,10 @@ SYMBOLS = (
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev",
     "gpmi_interp_free", "gpmi_logml_grad",
     "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
-    "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak",
+    "gpmi_last_timing", "gpmi_kernel_timing",
 )
+# additionally exported by the probe build (libgpmi_probes.so, -DGPMI_PROBES; tools/ only)
+PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak")
 
 
 class GpmiError(RuntimeError):
@@ -72,17 +75,20 @@ def _share_hip_runtime_with_torch():
 
 
 def load():
-    """Load libgpmi.so; loud failure when it has not been built."""
+    """Load libgpmi.so; loud failure when it has not been built.  GPMI_USE_PROBES=1 (tools/ only)
+    loads the probe build instead: same library plus the A/B kernels and gpmi_probe_* entry points."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise GpmiError(-4, "%s not found: build it with `python -m gp_amd._build` "
-                        "(hipcc --offload-arch=gfx950); gp_amd has no CPU fallback" % LIB_PATH)
+    probes = os.environ.get("GPMI_USE_PROBES", "") == "1"
+    path = PROBES_LIB_PATH if probes else LIB_PATH
+    if not os.path.exists(path):
+        raise GpmiError(-4, "%s not found: build it with `python -m gp_amd._build%s` "
+                        "(hipcc --offload-arch=gfx950); gp_amd has no CPU fallback" % (path, " --probes" if probes else ""))
     _share_hip_runtime_with_torch()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.gpmi_last_error.restype = C.c_char_p
-    for name in SYMBOLS:
+    for name in SYMBOLS + (PROBE_SYMBOLS if probes else ()):
         fn = getattr(lib, name)
         if name != "gpmi_last_error":
             fn.restype = C.c_int
@@ -368,22 +374,28 @@ class Context:
     def potrf_dev(self, dA_ptr, n, lda, dinfo_ptr):
         _chk(self._lib.gpmi_potrf_dev(self._h, C.c_void_p(dA_ptr), int(n), int(lda), C.c_void_p(dinfo_ptr)))
 
-    # ---- diagnostics ----------------------------------------------------------
+    # ---- probes (libgpmi_probes.so only: GPMI_USE_PROBES=1, tools/) -------------
+    def _probe(self, name):
+        fn = getattr(self._lib, name, None)
+        if fn is None:
+            raise GpmiError(-1, "%s exists in the probe build only (GPMI_USE_PROBES=1, python -m gp_amd._build --probes)" % name)
+        return fn
+
     def probe_mfma(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
         out = np.empty((16, 16))
-        _chk(self._lib.gpmi_probe_mfma(self._h, _p(A), _p(B), _p(out)))
+        _chk(self._probe("gpmi_probe_mfma")(self._h, _p(A), _p(B), _p(out)))
         return out
 
     def probe_syrk(self, m, k, reps=5):
         """(avg ms per launch, TFLOP/s at m(m+1)k algorithmic flops)."""
         ms = C.c_double(0.0)
-        _chk(self._lib.gpmi_probe_syrk(self._h, int(m), int(k), int(reps), C.byref(ms)))
+        _chk(self._probe("gpmi_probe_syrk")(self._h, int(m), int(k), int(reps), C.byref(ms)))
         return ms.value, m * (m + 1.0) * k / (ms.value * 1e-3) / 1e12
 
     def probe_mfma_peak(self, iters=20000):
         t = C.c_double(0.0); mhz = C.c_double(0.0)
-        _chk(self._lib.gpmi_probe_mfma_peak(self._h, int(iters), C.byref(t), C.byref(mhz)))
+        _chk(self._probe("gpmi_probe_mfma_peak")(self._h, int(iters), C.byref(t), C.byref(mhz)))
         return t.value, mhz.value
 
 

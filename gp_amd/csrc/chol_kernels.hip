@@ -914,8 +914,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
     // bits 24+ of `stagger` are probe-only switches (tools/syrk_bench.py): 1 = skip the C
     // epilogue, 2 = skip the operand streaming of the main loop; used for the cost breakdown
-    // in DESIGN.md, never set by the library itself
+    // in DESIGN.md.  They exist in the probe build only; here they fold to nothing.
+#ifdef GPMI_PROBES
     const int dbg = stagger >> 24;
+#else
+    constexpr int dbg = 0;
+#endif
     stagger_start(smem, stagger);
     int ti, tj;
     if (MODE == 1) {
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     }
 }
 
+#ifdef GPMI_PROBES  // A/B kernels of tools/ (libgpmi_probes.so); the product library ships without them
 // Persistent SYRK: at most two workgroups per CU are launched and each pulls tiles from a
 // counter until none is left.
 //  * Software CU reservation: a workgroup that finds itself on CU 0 of shader engine 0 of its
@@ -1400,6 +1405,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm9(const double *__restrict__ A, 
     }
 }
 
+#endif  // GPMI_PROBES
+
 // Packed factors (Fpack) of an ALREADY factored diagonal block: -L tiles in fragment
 // order and the inverse of every 16x16 diagonal tile.  Used by solves against a given L.
 __global__ __launch_bounds__(512) void k_pack_factors(const double *__restrict__ L11, size_t ldl,
@@ -1512,6 +1519,7 @@ __global__ __launch_bounds__(256) void k_trmv_lower_sum(const double *__restrict
     f[i] = s;
 }
 
+#ifdef GPMI_PROBES
 // D = A(16x4) * B(4x16) with the library's operand conventions (layout probe)
 __global__ void k_probe_mfma(const double *A, const double *B, double *D)
 {
@@ -1545,41 +1553,57 @@ __global__ __launch_bounds__(256) void k_probe_peak(double *sink, int iters)
         sink[9 + 2 * blockIdx.x] = (double)(r1 - r0);
     }
 }
+#endif  // GPMI_PROBES
 
 }  // namespace
 
 // ---------------------------------------------------------------------------
 // host-side drivers
 // ---------------------------------------------------------------------------
-int g_syrk_order = 0;    // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
-int g_gemm_variant = 3;
-int g_rect_auto = 0;      // 1: small rectangular launches use the ring kernel (measured: no gain)
-int g_stagger = (2 << 16) | 4;       // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup  // 0: v1 (4 waves, RMW epilogue), 1: v2 (8 waves, prefetched C)
+void gpmi_tuning_defaults(gpmi_tuning *t)
+{
+    t->syrk_order = 0;
+    t->stagger = (2 << 16) | 4;
+    t->fuse_diag = 7;
+    t->diag_waves = 5;
+    t->nb_adapt = 0;
+    t->ksplit = 1;
+    t->ksplit_max = 100;
+    t->block_recursive = 1;
+    t->se_nt = 1;
+    t->gemm_variant = 3;
+    t->rect_auto = 0;
+    t->syrk_persist = 0;
+}
 
-void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
+void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus)
 {
     if (M <= 0 || N <= 0 || K <= 0) return;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
+#ifdef GPMI_PROBES
     // Launches with fewer tiles than workgroup slots are latency-bound (one tile per CU, every
     // k-step exposes the DMA latency): the 3-buffer-ring kernel (DMA two steps ahead, C tile
     // prefetched) has the shorter per-tile time there; the 2-workgroup-per-CU kernel wins once
     // several rounds of tiles keep each CU's pair of workgroups busy.
-    const bool few_tiles = g_rect_auto && (int)(grid.x * grid.y) <= 384;
-    if (g_gemm_variant == 2 || (g_gemm_variant == 3 && few_tiles)) {
+    const bool few_tiles = c->tune.rect_auto && (int)(grid.x * grid.y) <= 384;
+    if (c->tune.gemm_variant == 2 || (c->tune.gemm_variant == 3 && few_tiles)) {
         if (accumulate_minus)
             hipLaunchKernelGGL(k_gemm9<0>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
         else
             hipLaunchKernelGGL(k_gemm9<2>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
         return;
     }
-    if (g_gemm_variant == 1) {
+    if (c->tune.gemm_variant == 1) {
         if (accumulate_minus)
             hipLaunchKernelGGL(k_gemm8<0>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
         else
             hipLaunchKernelGGL(k_gemm8<2>, grid, 512, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0);
         return;
     }
+#else
+    (void)c;
+#endif
     if (accumulate_minus)
         hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{}, KSplit{});
     else
@@ -1592,17 +1616,17 @@ void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B,
 // 24.55 / 4.02 -- with both, no one-workgroup kernel is left that has to find a free CU next to the
 // other lanes' updates.  One evaluation at a time: neutral (the block's tile sits on the critical
 // path either way).
-int g_fuse_diag = 7;  // bit 2: sub-tiled diagonal tile in the fused in-block GEMMs
+// (tune.fuse_diag, default 7; bit 2: sub-tiled diagonal tile in the fused in-block GEMMs)
 
 // C -= A B^T with the default kernel and the diagonal block at C's origin factored by the
 // workgroup of tile (0, 0).  false: this configuration cannot fuse (caller launches the
 // diagonal kernel itself and uses launch_gemm_nt).
-static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb, double *C,
+static bool launch_gemm_nt_fused(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb, double *C,
                                  size_t ldc, int M, int N, int K, const FuseDiag &fd)
 {
-    if (!(g_fuse_diag & 1) || (g_gemm_variant != 3 && g_gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
+    if (!(c->tune.fuse_diag & 1) || (c->tune.gemm_variant != 3 && c->tune.gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
-    if ((g_fuse_diag & 4) && fd.ctr && M >= GT && N >= GT && K % 32 == 0) {  // tile (0, 0) interior: sub-tiled
+    if ((c->tune.fuse_diag & 4) && fd.ctr && M >= GT && N >= GT && K % 32 == 0) {  // tile (0, 0) interior: sub-tiled
         hipLaunchKernelGGL(k_gemm_nt<0>, dim3(grid.x * grid.y + 2), 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0x200, 0, fd, KSplit{});
         return true;
     }
@@ -1610,19 +1634,17 @@ static bool launch_gemm_nt_fused(hipStream_t s, const double *A, size_t lda, con
     return true;
 }
 
-int g_diag_waves = 5;    // 5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
-int g_syrk_persist = 0;  // 0: one workgroup per tile; 1: persistent workgroups; 2: persistent + CU reservation
-int g_nb_adapt = 0;      // 1: auto outer-block width chosen per block from the columns still to factor (measured: -0.2 ms sequential at N = 16384, nothing with lanes)
-
-// returns true when fd was given and the launch factors the diagonal block at C's origin
-int g_ksplit = 1;        // quadrant split of the tail-round tiles of a SYRK launch (see KSplit)
-// ... when at most this many tiles are left for the last round.  Whole tiles of a round this thin run
+// tune.diag_waves  5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
+// tune.nb_adapt    1: auto outer-block width chosen per block from the columns still to factor (measured: -0.2 ms
+//                  sequential at N = 16384, nothing with lanes)
+// tune.ksplit      quadrant split of the tail-round tiles of a SYRK launch (see KSplit) ...
+// tune.ksplit_max  ... when at most this many tiles are left for the last round.  Whole tiles of a round this thin run
 // alone on their CUs (~115 us at K = 1024 instead of ~250 us shared); four quadrant workgroups take
 // ~75 us as long as they, too, have CUs of their own (4 R <= ~400).  Measured per launch (K = 1024):
 // R = 16..92: -0.04 .. -0.065 ms; R = 136..340: +0.03 .. +0.06 ms.
-int g_ksplit_max = 100;
 
-static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
+// returns true when fd was given and the launch factors the diagonal block at C's origin
+static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int M,
                               int N, int K, int *ctr, int ncu, int tri = 0, const FuseDiag *fd = nullptr)
 {
     if (tri && M > 0 && N > 0 && K > 0) {  // upper-triangular panel: plain kernel, row-major tiles, zero K-range skipped
@@ -1633,36 +1655,41 @@ static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
     }
     if (M <= 0 || N <= 0 || K <= 0) return false;
     const int T = (M + GT - 1) / GT;
-    const int ntiles = syrk_grid(T, g_syrk_order);
-    if (g_gemm_variant == 2) {
-        hipLaunchKernelGGL(k_gemm9<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+    const int syrk_order = c->tune.syrk_order;
+    const int ntiles = syrk_grid(T, syrk_order);
+    const int stg = ntiles >= 1024 ? c->tune.stagger : 0;  // only when every CU holds two workgroups for many rounds
+#ifdef GPMI_PROBES
+    if (c->tune.gemm_variant == 2) {
+        hipLaunchKernelGGL(k_gemm9<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, syrk_order);
         return false;
     }
-    if (g_gemm_variant == 1) {
-        hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order);
+    if (c->tune.gemm_variant == 1) {
+        hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, syrk_order);
         return false;
     }
-    const int stg = ntiles >= 1024 ? g_stagger : 0;  // only when every CU holds two workgroups for many rounds
-    if (g_syrk_persist && ctr) {
+    if (c->tune.syrk_persist && ctr) {
         const int slots = 2 * (ncu > 0 ? ncu : 256);
         const int grid = ntiles < slots ? ntiles : slots;
         // reservation only for launches that would otherwise hold every CU for a long time
-        const int budget = (g_syrk_persist == 2 && ntiles >= 2 * slots) ? 16 : 0;
-        hipLaunchKernelGGL(k_syrk_persist, dim3(grid), 256, 0, s, P, ldp, C, ldc, M, N, K, g_syrk_order, stg, ntiles,
+        const int budget = (c->tune.syrk_persist == 2 && ntiles >= 2 * slots) ? 16 : 0;
+        hipLaunchKernelGGL(k_syrk_persist, dim3(grid), 256, 0, s, P, ldp, C, ldc, M, N, K, syrk_order, stg, ntiles,
                            budget, ctr);
         return false;
     }
+#else
+    (void)ctr;
+#endif
     // tile (0, 0) is block 0 only in the row-major order
     // only in launches of more than one round of tiles, where workgroup 0's extra 27 us do not
     // lengthen the kernel
     const int slots = 2 * (ncu > 0 ? ncu : 256);
-    const bool fuse = fd && fd->Fp && (g_fuse_diag & 2) && g_syrk_order == 0 && ntiles > slots;
+    const bool fuse = fd && fd->Fp && (c->tune.fuse_diag & 2) && syrk_order == 0 && ntiles > slots;
     KSplit ks{};
     int grid = ntiles;
-    if (g_ksplit && g_syrk_order == 0 && K % GK == 0) {
+    if (c->tune.ksplit && syrk_order == 0 && K % GK == 0) {
         int first = ntiles;  // first tile computed as quadrants
         const int bfull = (ntiles / slots) * slots, R = ntiles - bfull;
-        if (R > 0 && R <= g_ksplit_max) first = bfull;
+        if (R > 0 && R <= c->tune.ksplit_max) first = bfull;
         // A last tile row with few valid rows -- the augmented row y^T of the marginal likelihood makes
         // every trailing update end in a row of T tiles with ONE valid row -- costs a whole tile time
         // per tile (2.4 % of all tiles at N = 16384); as quadrants only the MFMA tiles that hold
@@ -1674,24 +1701,25 @@ static bool launch_syrk_lower(hipStream_t s, const double *P, size_t ldp, double
             grid = first + 4 * (ntiles - first);
         }
     }
-    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(grid), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, g_syrk_order, stg,
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(grid), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, syrk_order, stg,
                        fuse ? *fd : FuseDiag{}, ks);
     return fuse;
 }
 
-void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
-                       int ncu)
+#ifdef GPMI_PROBES
+void launch_syrk_probe(const gpmi_ctx *c, hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k)
 {
-    launch_syrk_lower(s, P, ldp, C, ldc, m, m, k, ctr, ncu);
+    launch_syrk_lower(c, s, P, ldp, C, ldc, m, m, k, c->d_ctr, c->ncu);
 }
+#endif
 
 // C(lower) -= U U^T for an upper-triangular n x n U
-void launch_syrk_uut(hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n)
+void launch_syrk_uut(const gpmi_ctx *c, hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n)
 {
-    launch_syrk_lower(s, U, ldu, C, ldc, n, n, n, nullptr, 0, 1);
+    launch_syrk_lower(c, s, U, ldu, C, ldc, n, n, n, nullptr, 0, 1);
 }
 
-int g_block_recursive = 1;  // 1: in-block updates by recursive halving; 0: 128 / 256 / rest-of-block levels
+// tune.block_recursive  1: in-block updates by recursive halving; 0: 128 / 256 / rest-of-block levels
 
 // One 128-column panel [k, k + kb): diagonal block, then the rows [max(k + kb, row_lo), row_hi) below it.
 static double *fpack_slot(gpmi_ctx *c, double *Fpack_all, int ko, int k)
@@ -1705,7 +1733,7 @@ static void panel_one(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
 {
     double *Fp = fpack_slot(c, Fpack_all, ko, k);
     if (with_diag) {
-        if (g_diag_waves == 4)
+        if (c->tune.diag_waves == 4)
             hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
         else
             hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
@@ -1738,10 +1766,10 @@ static void panel_rec(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
         double *C = W + (size_t)rlo + (size_t)km * ld;
         if (with_diag && rlo == km) {  // C starts at the next panel's diagonal block: factor it in this launch
             const int kb = (k1 - km < NB) ? k1 - km : NB;
-            fused = launch_gemm_nt_fused(s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0,
+            fused = launch_gemm_nt_fused(c, s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0,
                                          FuseDiag{fpack_slot(c, Fpack_all, ko, km), d_info, km, kb, c->d_ctr + 8});
         }
-        if (!fused) launch_gemm_nt(s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0, 1);
+        if (!fused) launch_gemm_nt(c, s, A, ld, B, ld, C, ld, row_hi - rlo, k1 - km, km - k0, 1);
     }
     panel_rec(c, W, ld, d_info, Fpack_all, ko, km, k1, row_lo, row_hi, with_diag, fused, s);
 }
@@ -1752,13 +1780,13 @@ static void panel_rec(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
 //   (0, M, true)   : the whole panel phase, full height
 //   (0, ke, true)  : only the NBO x NBO diagonal block -- the latency chain of the look-ahead
 //   (ke, M, false) : the rows below it -- wide, throughput-bound kernels
-// g_block_recursive == 0 keeps the earlier three fixed levels: 128-column panels grouped into
+// tune.block_recursive == 0 keeps the earlier three fixed levels: 128-column panels grouped into
 // middle blocks of NBM columns; a panel's K = 128 update reaches only to the end of its middle
 // block, the rest of the outer block is updated once per middle block with K = NBM.
 static void panel_rows(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fpack_all, int ko, int ke, int NBO,
                        int row_lo, int row_hi, bool with_diag, hipStream_t s, bool first_diag_done = false)
 {
-    if (g_block_recursive) {
+    if (c->tune.block_recursive) {
         panel_rec(c, W, ld, d_info, Fpack_all, ko, ko, ke, row_lo, row_hi, with_diag, first_diag_done, s);
         return;
     }
@@ -1773,12 +1801,12 @@ static void panel_rows(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *F
             const int rlo = r0 > row_lo ? r0 : row_lo;
             if (rlo >= row_hi) continue;
             if (r0 < kme)  // rest of this middle block: rows [rlo, row_hi) x cols [r0, kme), K = kb
-                launch_gemm_nt(s, W + (size_t)rlo + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
+                launch_gemm_nt(c, s, W + (size_t)rlo + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld,
                                W + (size_t)rlo + (size_t)r0 * ld, ld, row_hi - rlo, kme - r0, kb, 1);
         }
         const int rlo = kme > row_lo ? kme : row_lo;
         if (kme < ke && rlo < row_hi)  // rest of the outer block: cols [kme, ke), K = kme - km
-            launch_gemm_nt(s, W + (size_t)rlo + (size_t)km * ld, ld, W + (size_t)kme + (size_t)km * ld, ld,
+            launch_gemm_nt(c, s, W + (size_t)rlo + (size_t)km * ld, ld, W + (size_t)kme + (size_t)km * ld, ld,
                            W + (size_t)rlo + (size_t)kme * ld, ld, row_hi - rlo, ke - kme, kme - km, 1);
     }
 }
@@ -1795,11 +1823,11 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     const bool la = c->lookahead > 0 && c->pstream && nfac > NBO && NBO / GPMI_NB <= GPMI_FPACK_SLOTS;
     if (!la) {
         hipStream_t s = c->stream;
-        // auto width follows the columns still to factor (g_nb_adapt): the last blocks of a large
+        // auto width follows the columns still to factor (tune.nb_adapt): the last blocks of a large
         // matrix are a small matrix, whose few trailing tiles do not fill the chip at K = 1024
         bool diag_done = false;
         for (int ko = 0, nbo = NBO; ko < nfac; ko += nbo) {
-            nbo = (c->nb_outer > 0 || !g_nb_adapt) ? NBO : nbo_for(nfac - ko);
+            nbo = (c->nb_outer > 0 || !c->tune.nb_adapt) ? NBO : nbo_for(nfac - ko);
             const int ke = (ko + nbo < nfac) ? ko + nbo : nfac;
             kt_begin(c, 2, s);
             panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, nbo, 0, M, true, s, diag_done);
@@ -1815,7 +1843,7 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             if (ke < nfac)
                 fd = FuseDiag{fpack_slot(c, Fpack_all, ke, ke), d_info, ke, (nfac - ke < GPMI_NB) ? nfac - ke : GPMI_NB, nullptr};
             kt_begin(c, 1, s);
-            diag_done = launch_syrk_lower(s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
+            diag_done = launch_syrk_lower(c, s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
                                           M - ke, ncol - ke, ke - ko, c->d_ctr, c->ncu, 0, &fd);
             // algorithmic flops: lower triangle (incl. diagonal) of the square part + extra rows
             kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(ke - ko), s);
@@ -1849,20 +1877,20 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             if (ke >= M || ke >= ncol) continue;
             if (ke < nfac) {
                 const int ke2 = (ke + NBO < nfac) ? ke + NBO : nfac;
-                launch_syrk_lower(sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
+                launch_syrk_lower(c, sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
                                   ke2 - ke, ke2 - ke, K, c->d_ctr, c->ncu);
                 hipEventRecord(c->evU, sb);
                 hipStreamWaitEvent(sc, c->evU, 0);
                 panel_rows(c, W, ld, d_info, Fpack_all, ke, ke2, NBO, 0, ke2, true, sc);
                 hipEventRecord(c->evP, sc);
                 if (ke2 < M)
-                    launch_gemm_nt(sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ko * ld, ld,
+                    launch_gemm_nt(c, sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ko * ld, ld,
                                    W + (size_t)ke2 + (size_t)ke * ld, ld, M - ke2, ke2 - ke, K, 1);
                 if (ke2 < M && ke2 < ncol)
-                    launch_syrk_lower(sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke2 + (size_t)ke2 * ld,
+                    launch_syrk_lower(c, sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke2 + (size_t)ke2 * ld,
                                       ld, M - ke2, ncol - ke2, K, c->d_ctr, c->ncu);
             } else {  // last factored block: Schur complement / augmented rows
-                launch_syrk_lower(sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
+                launch_syrk_lower(c, sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
                                   M - ke, ncol - ke, K, c->d_ctr, c->ncu);
             }
         }
@@ -1881,7 +1909,7 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
 // at K in the thousands instead of K = 128), solve the right half.  upper_tri: X[i][j] = 0 for i > j --
 // column block [c0, c1) has rows [0, c1) only, and the product skips the zero columns of its
 // trapezoidal A operand per row-tile.
-static void trsm_right_rec(hipStream_t s, const double *L, size_t ldl, double *X, size_t ldx, int mrows,
+static void trsm_right_rec(const gpmi_ctx *c, hipStream_t s, const double *L, size_t ldl, double *X, size_t ldx, int mrows,
                            const double *Fpack_all, int upper_tri, int c0, int c1)
 {
     const int NB = GPMI_NB;
@@ -1893,18 +1921,18 @@ static void trsm_right_rec(hipStream_t s, const double *L, size_t ldl, double *X
     }
     const int npan = (c1 - c0 + NB - 1) / NB;
     const int cm = c0 + ((npan + 1) / 2) * NB;
-    trsm_right_rec(s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, c0, cm);
+    trsm_right_rec(c, s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, c0, cm);
     const int mr = (upper_tri && cm < mrows) ? cm : mrows;  // rows where X[:, c0:cm] is non-zero
     const double *A = X + (size_t)c0 * ldx, *B = L + (size_t)cm + (size_t)c0 * ldl;
     double *C = X + (size_t)cm * ldx;
-    if (upper_tri && (g_gemm_variant == 3 || g_gemm_variant == 0)) {
+    if (upper_tri && (c->tune.gemm_variant == 3 || c->tune.gemm_variant == 0)) {
         dim3 grid((c1 - cm + GT - 1) / GT, (mr + GT - 1) / GT);  // x: column tiles, y: row tiles (long K first)
         hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 0x100, 0,
                            FuseDiag{nullptr, nullptr, c0, 0, nullptr}, KSplit{});
     } else {
-        launch_gemm_nt(s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 1);
+        launch_gemm_nt(c, s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 1);
     }
-    trsm_right_rec(s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, cm, c1);
+    trsm_right_rec(c, s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, cm, c1);
 }
 
 int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
@@ -1919,7 +1947,7 @@ int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X
     // N ~ 12k on (value + gradient at N = 16384: 88.9 -> 83.2 ms; N = 8192: 16.0 vs 16.5 ms, N = 4096:
     // 4.5 vs 5.2 ms -- unequal tile lengths and more launches)
     if (mrows >= 2 * GT && n > NB && (!upper_tri || n >= 12288)) {
-        trsm_right_rec(s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, 0, n);
+        trsm_right_rec(c, s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, 0, n);
     } else {  // a few rows (triangular solve of vectors): one pass over L, panel by panel
         for (int k = 0; k < n; k += NB) {
             const int kb = (n - k < NB) ? n - k : NB;
@@ -1928,7 +1956,7 @@ int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X
             hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)k * ldx, ldx, 0, mr, kb, Fp);
             const int r0 = k + kb;
             if (r0 < n)
-                launch_gemm_nt(s, X + (size_t)k * ldx, ldx, L + (size_t)r0 + (size_t)k * ldl, ldl,
+                launch_gemm_nt(c, s, X + (size_t)k * ldx, ldx, L + (size_t)r0 + (size_t)k * ldl, ldl,
                                X + (size_t)r0 * ldx, ldx, mr, n - r0, kb, 1);
         }
     }
@@ -1969,6 +1997,7 @@ void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const 
     hipLaunchKernelGGL(k_trmv_lower_sum, dim3((n + 255) / 256), 256, 0, s, part, n, nchunk, f);
 }
 
+#ifdef GPMI_PROBES
 void launch_probe_mfma(hipStream_t s, const double *A, const double *B, double *D)
 {
     hipLaunchKernelGGL(k_probe_mfma, dim3(1), 64, 0, s, A, B, D);
@@ -1980,3 +2009,4 @@ void launch_probe_peak(hipStream_t s, double *sink, int iters, int *blocks, int 
     *threads = 256;
     hipLaunchKernelGGL(k_probe_peak, dim3(*blocks), 256, 0, s, sink, iters);
 }
+#endif  // GPMI_PROBES

@@ -140,6 +140,7 @@ static int streams_concurrent(gpmi_ctx *c, hipStream_t a, hipStream_t b, bool *c
     return 0;
 }
 
+#ifdef GPMI_PROBES
 static int full_mask_stream(gpmi_ctx *c, hipStream_t *out)
 {
     hipDeviceProp_t prop;
@@ -152,6 +153,7 @@ static int full_mask_stream(gpmi_ctx *c, hipStream_t *out)
     HIPCHK(hipStreamSynchronize(*out));
     return 0;
 }
+#endif
 
 // up to 4 dedicated streams that are pairwise concurrent (one per pipe)
 static int calibrate_streams(gpmi_ctx *c)
@@ -160,10 +162,13 @@ static int calibrate_streams(gpmi_ctx *c)
     int nq = 0, rc;
     for (int i = 0; i < 10 && nq < 4; ++i) {
         hipStream_t cand;
+#ifdef GPMI_PROBES
         const char *kind = getenv("GPMI_CAL_KIND");  // experiment: 1 = dedicated (CU-mask API) queues
         if (kind && atoi(kind) == 1) {
             if ((rc = full_mask_stream(c, &cand))) return rc;
-        } else {
+        } else
+#endif
+        {
             HIPCHK(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
             hipLaunchKernelGGL(k_cal_short, dim3(1), 64, 0, cand, c->d_info + 8);  // binds the hardware queue
             HIPCHK(hipStreamSynchronize(cand));
@@ -246,6 +251,7 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
     if (!c) return gpmi_fail(GPMI_ENOMEM, "host allocation failed");
     c->device = device;
     c->pid = (int)getpid();
+    gpmi_tuning_defaults(&c->tune);
     c->nb_outer = 0;  // auto
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
@@ -361,61 +367,51 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         else c->cu_mask_mode = value;
         return c->lookahead > 0 ? ensure_mstream(c) : 0;
     }
-    if (!strcmp(name, "rect_auto")) {
-        extern int g_rect_auto;
-        g_rect_auto = value;
-        return 0;
-    }
     if (!strcmp(name, "stagger")) {
-        extern int g_stagger;
-        g_stagger = value;
+        c->tune.stagger = value;
         return 0;
     }
     if (!strcmp(name, "diag_waves")) {
-        extern int g_diag_waves;
         if (value != 4 && value != 5) return gpmi_fail(GPMI_EARG, "diag_waves must be 4 or 5");
-        g_diag_waves = value;
-        return 0;
-    }
-    if (!strcmp(name, "syrk_persist")) {
-        extern int g_syrk_persist;
-        g_syrk_persist = value;
+        c->tune.diag_waves = value;
         return 0;
     }
     if (!strcmp(name, "se_nt")) {
-        extern int g_se_nt;
-        g_se_nt = value != 0;
+        c->tune.se_nt = value != 0;
         return 0;
     }
     if (!strcmp(name, "ksplit")) {  // 0: off; 1: on; R > 1: on, split the tail round when it holds <= R tiles
-        extern int g_ksplit, g_ksplit_max;
-        g_ksplit = value != 0;
-        if (value > 1) g_ksplit_max = value;
+        c->tune.ksplit = value != 0;
+        if (value > 1) c->tune.ksplit_max = value;
         return 0;
     }
     if (!strcmp(name, "fuse_diag")) {
-        extern int g_fuse_diag;
-        g_fuse_diag = value;
+        c->tune.fuse_diag = value;
         return 0;
     }
     if (!strcmp(name, "block_recursive")) {
-        extern int g_block_recursive;
-        g_block_recursive = value != 0;
+        c->tune.block_recursive = value != 0;
         return 0;
     }
     if (!strcmp(name, "nb_adapt")) {
-        extern int g_nb_adapt;
-        g_nb_adapt = value != 0;
+        c->tune.nb_adapt = value != 0;
         return 0;
     }
     if (!strcmp(name, "syrk_order")) {
-        extern int g_syrk_order;
-        g_syrk_order = value;
+        c->tune.syrk_order = value != 0;
+        return 0;
+    }
+#ifdef GPMI_PROBES
+    if (!strcmp(name, "rect_auto")) {
+        c->tune.rect_auto = value;
+        return 0;
+    }
+    if (!strcmp(name, "syrk_persist")) {
+        c->tune.syrk_persist = value;
         return 0;
     }
     if (!strcmp(name, "gemm_variant")) {
-        extern int g_gemm_variant;
-        g_gemm_variant = value;
+        c->tune.gemm_variant = value;
         return 0;
     }
     if (!strcmp(name, "debug_topology")) {  // prints which of the context's streams dispatch concurrently
@@ -435,6 +431,7 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         }
         return 0;
     }
+#endif  // GPMI_PROBES
     if (!strcmp(name, "calibrate")) {
         c->calibrate = value != 0;
         return 0;
@@ -577,7 +574,7 @@ extern "C" int gpmi_se_cov_dev(gpmi_ctx *c, const double *dX, int n, int ldx, co
     SeParams p;
     int rc = fill_params(&p, D, alpha, ell, n_ell);
     if (rc) return rc;
-    launch_se_cov(c->stream, dX, n, ldx, dY, m, ldy, p, diag_add, (flags & GPMI_LOWER) ? 1 : 0, dK, (size_t)ldk);
+    launch_se_cov(c, c->stream, dX, n, ldx, dY, m, ldy, p, diag_add, (flags & GPMI_LOWER) ? 1 : 0, dK, (size_t)ldk);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -787,7 +784,7 @@ static int logml_core(gpmi_ctx *c, const double *dX, int n, int ldx, const doubl
     tic(c, 0);
     HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), c->stream));
     kt_begin(c, 0);
-    launch_se_cov(c->stream, dX, n, ldx, nullptr, n, ldx, p, diag_add, 1, c->W, ld);
+    launch_se_cov(c, c->stream, dX, n, ldx, nullptr, n, ldx, p, diag_add, 1, c->W, ld);
     kt_end(c, 0, 4.0 * (double)n * ((double)n + 1.0));  // lower triangle incl. diagonal, 8 B each
     launch_set_row(c->stream, c->W, ld, n, dy, n, n);
     tic(c, 1);
@@ -833,6 +830,7 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
             if (rc) return rc;
         }
         gpmi_ctx *lc = c->lane[l - 1];
+        lc->tune = c->tune;
         lc->nb_outer = c->nb_outer;
         lc->lookahead = c->lane_lookahead;  // default 0: concurrent lanes already fill the panel phases
         if (c->lane_lookahead) {
@@ -982,6 +980,7 @@ extern "C" int gpmi_joint_logml(gpmi_ctx *c, const double *t, int n, const doubl
 }
 
 // ---- rbf_cov_chol (covariance.cpp:9-47) ---------------------------------------
+namespace {
 __global__ void k_rbf_dsigma(const double *__restrict__ x, int n, double l, double *__restrict__ S, size_t ld)
 {
     // dSigma/dl = Sigma * (xi-xj)^2 / l^3  (tangent of covariance.cpp:19 with dl = 1, :13)
@@ -996,6 +995,7 @@ __global__ void k_rbf_dsigma(const double *__restrict__ x, int n, double l, doub
         S[(size_t)i + (size_t)j * ld] = exp(-r2 / (2 * l * l)) * r2 / (l * l * l);
     }
 }
+}  // namespace
 
 // device core: x resident in dx; on return (stream order) Lc holds L (zero upper) and S holds dL/dl,
 // both n x n with leading dimension ldd in the context's staging buffers 3 and 1
@@ -1018,7 +1018,7 @@ static int rbf_cov_chol_core(gpmi_ctx *c, const double *dx, int n, double l, dou
     SeParams p;
     double ell = l;
     if ((rc = fill_params(&p, 1, 1.0, &ell, 1))) return rc;
-    launch_se_cov(s, dx, n, n, nullptr, n, n, p, 1e-10, 1, c->W, ld);
+    launch_se_cov(c, s, dx, n, n, nullptr, n, n, p, 1e-10, 1, c->W, ld);
     if ((rc = launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, Fall))) return rc;
     launch_copy_matrix(s, c->W, ld, Lc, (size_t)ldd, n, n, 1);
     // tangent: Ldot = L Phi(L^-1 Sdot L^-T), Phi = lower triangle with halved diagonal
@@ -1027,7 +1027,7 @@ static int rbf_cov_chol_core(gpmi_ctx *c, const double *dx, int n, double l, dou
     launch_transpose(s, S, (size_t)ldd, S2, (size_t)ldd, n, n);                                  // S2 = L^-1 Sdot
     if ((rc = launch_trsm_right(c, Lc, (size_t)ldd, n, S2, (size_t)ldd, n, Fall))) return rc;    // S2 <- L^-1 Sdot L^-T
     launch_phi_mask(s, S2, (size_t)ldd, n);                                                       // Phi^T (upper)
-    launch_gemm_nt(s, Lc, (size_t)ldd, S2, (size_t)ldd, S, (size_t)ldd, n, n, n, 0);              // S = L Phi
+    launch_gemm_nt(c, s, Lc, (size_t)ldd, S2, (size_t)ldd, S, (size_t)ldd, n, n, n, 0);              // S = L Phi
     HIPCHK(hipGetLastError());
     *Lc_out = Lc;
     *S_out = S;
@@ -1324,10 +1324,6 @@ __global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ 
 }
 }  // namespace
 
-void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
-                       int ncu);
-void launch_syrk_uut(hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n);
-
 extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
                                double alpha, const double *ell, int n_ell, double sigma, double jitter,
                                double *out3, double *grad)
@@ -1355,7 +1351,7 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     hipStream_t s = c->stream;
     // factorisation with the augmented row, all panel factors kept
     HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
-    launch_se_cov(s, dX, n, n, nullptr, n, n, p, sigma * sigma + jitter, 1, c->W, ld);
+    launch_se_cov(c, s, dX, n, n, nullptr, n, n, p, sigma * sigma + jitter, 1, c->W, ld);
     launch_set_row(s, c->W, ld, n, dy, n, n);
     if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, Fall))) return rc;
     launch_logml_finalize(s, c->W, ld, n, n, c->d_info, c->d_out, c->d_info + 1);
@@ -1367,7 +1363,7 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     hipLaunchKernelGGL(k_upper_mv_sum, dim3((n + 255) / 256), 256, 0, s, mvpart, n, nchunk, av);
     // W(lower) = -U U^T = -K^-1
     HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
-    launch_syrk_uut(s, U, ldu, c->W, ld, n);
+    launch_syrk_uut(c, s, U, ldu, c->W, ld, n);
     hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, n, p, av, c->W, ld, part);
     hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, sums);
     HIPCHK(hipGetLastError());
@@ -1705,7 +1701,7 @@ extern "C" int gpmi_seq_create(gpmi_ctx *c, gpmi_seq **out, const double *X, int
     if ((e = hipMemsetAsync(q->row2, 0, (2 * ((size_t)n + 1) + 4096) * sizeof(double), s)) != hipSuccess)
         return fail_hip(e, "memset");
     // K~ = K_XX + jitter I (:50,55), L = chol(K~) kept with its packed block factors
-    launch_se_cov(s, q->dX, n, n, nullptr, n, n, p, jitter, 1, c->W, ld);
+    launch_se_cov(c, s, q->dX, n, n, nullptr, n, n, p, jitter, 1, c->W, ld);
     SEQ_TRY(launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, q->Fall))
     launch_copy_matrix(s, c->W, ld, q->L, ldm, n, n, 1);
     // G^T = L^-1 Kn^T L^-T: (Kn L^-T), transposed, times L^-T again;  B = I - (G + G^T) / 2 (:76-77)
@@ -1746,7 +1742,7 @@ extern "C" int gpmi_seq_step(gpmi_seq *q, const double *xs, double *out2)
                             hipMemcpyHostToDevice, s));
     double *ti = q->Kx + (size_t)i * n;
     int rc;
-    launch_se_cov(s, q->dX, n, n, q->Xs + i, 1, ms, q->p, 0.0, 0, q->kcol, (size_t)n);  // K_XsX row (:71)
+    launch_se_cov(c, s, q->dX, n, n, q->Xs + i, 1, ms, q->p, 0.0, 0, q->kcol, (size_t)n);  // K_XsX row (:71)
     launch_set_row(s, q->row2, 2, 0, q->kcol, n, n);
     if ((rc = launch_trsm_right(c, q->L, q->ldm, n, q->row2, 2, 1, q->Fall))) return rc;  // t_i = L^-1 k_i
     launch_get_row(s, q->row2, 2, 0, 0, n, 1.0, ti);
@@ -1819,10 +1815,10 @@ extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
     return 0;
 }
 
+#ifdef GPMI_PROBES
 // Stand-alone trailing-update launch on synthetic data: C (m x m, lower) -= P P^T, P m x k.
 // `reps` back-to-back launches timed with HIP events; ms = average per launch.
-void launch_syrk_probe(hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k, int *ctr,
-                       int ncu);
+namespace {
 __global__ void k_fill(double *p, size_t n, double scale)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1831,6 +1827,7 @@ __global__ void k_fill(double *p, size_t n, double scale)
         p[i] = scale * ((double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5);
     }
 }
+}  // namespace
 extern "C" int gpmi_probe_syrk(gpmi_ctx *c, int m, int k, int reps, double *ms)
 {
     ENTER(c);
@@ -1842,9 +1839,9 @@ extern "C" int gpmi_probe_syrk(gpmi_ctx *c, int m, int k, int reps, double *ms)
     if ((rc = stage_buf(c, 3, ld * (size_t)(k + 1) * sizeof(double), &P))) return rc;
     hipLaunchKernelGGL(k_fill, dim3(2048), 256, 0, c->stream, c->W, ld * (size_t)m, 1.0);
     hipLaunchKernelGGL(k_fill, dim3(2048), 256, 0, c->stream, P, ld * (size_t)k, 1e-3);
-    launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k, c->d_ctr, c->ncu);
+    launch_syrk_probe(c, c->stream, P, ld, c->W, ld, m, k);
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    for (int r = 0; r < reps; ++r) launch_syrk_probe(c->stream, P, ld, c->W, ld, m, k, c->d_ctr, c->ncu);
+    for (int r = 0; r < reps; ++r) launch_syrk_probe(c, c->stream, P, ld, c->W, ld, m, k);
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
@@ -1898,3 +1895,4 @@ extern "C" int gpmi_probe_mfma_peak(gpmi_ctx *c, int iters, double *tflops, doub
     }
     return 0;
 }
+#endif  // GPMI_PROBES

@@ -18,9 +18,25 @@ struct SeParams {            // squared-exponential hyper-parameters, kernel-arg
     int D;
 };
 
+// Algorithm switches of one context (gpmi_set_option).  Per context, never process-global: two
+// contexts or two host threads do not change each other's algorithm; grid lanes copy their root's.
+struct gpmi_tuning {
+    int syrk_order;       // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
+    int stagger;          // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup of a CU pair
+    int fuse_diag;        // bit 0: in-block GEMMs, bit 1: trailing SYRK, bit 2: sub-tiled diagonal tile
+    int diag_waves;       // 5: k_potrf_diag, 4: k_potrf_diag4
+    int nb_adapt;
+    int ksplit, ksplit_max;
+    int block_recursive;
+    int se_nt;            // non-temporal stores in k_se_cov<>
+    int gemm_variant, rect_auto, syrk_persist;  // A/B kernels: honoured by the probe build (-DGPMI_PROBES) only
+};
+void gpmi_tuning_defaults(gpmi_tuning *t);
+
 struct gpmi_ctx {
     int device;
     int pid;
+    gpmi_tuning tune;
     hipStream_t own_stream;
     hipStream_t stream;      // stream in use (own or caller's)
     // factorisation workspace: column-major, leading dimension ld, ncols columns (+ slack)
@@ -89,7 +105,7 @@ int gpmi_fail(int code, const char *fmt, ...);
 
 // ---- kernel launchers (se_kernels.hip) -------------------------------------
 // K (n x m, ldk) from device points; Y == X when dY == nullptr.
-void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
+void launch_se_cov(const gpmi_ctx *c, hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
                    const SeParams &p, double diag_add, int lower, double *dK, size_t ldk);
 void launch_deriv_cov(hipStream_t s, int kind, const double *dx, int n, const double *dy, int m,
                       double a2, double l, int compat, int lower, double *dK, size_t ldk);
@@ -121,8 +137,9 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
 int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
                       int mrows, const double *Fpack_all, int upper_tri = 0);
 // C (M x N) = beta_is_one ? C - A B^T : A B^T   (A: M x K, B: N x K, column-major)
-void launch_gemm_nt(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
+void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus);
+void launch_syrk_uut(const gpmi_ctx *c, hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n);
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all);
 void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0, int m, double scale, double *out);
 void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
@@ -130,5 +147,8 @@ void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int
 int trmv_lower_chunks(int n);
 void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f,
                        double *part /* trmv_lower_chunks(n) * n doubles */);
+#ifdef GPMI_PROBES
+void launch_syrk_probe(const gpmi_ctx *c, hipStream_t s, const double *P, size_t ldp, double *C, size_t ldc, int m, int k);
 void launch_probe_mfma(hipStream_t s, const double *A, const double *B, double *D);
 void launch_probe_peak(hipStream_t s, double *sink, int iters, int *blocks, int *threads);
+#endif

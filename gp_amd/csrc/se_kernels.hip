@@ -387,9 +387,7 @@ __global__ void k_hermite_mv_sum(const double *__restrict__ part, int n, int nch
 }
 }  // namespace
 
-int g_se_nt = 1;
-
-void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
+void launch_se_cov(const gpmi_ctx *c, hipStream_t s, const double *dX, int n, int ldx, const double *dY, int m, int ldy,
                    const SeParams &p, double diag_add, int lower, double *dK, size_t ldk)
 {
     if (n <= 0 || m <= 0) return;
@@ -397,8 +395,7 @@ void launch_se_cov(hipStream_t s, const double *dX, int n, int ldx, const double
     if (same) { dY = dX; ldy = ldx; }
     dim3 grid((n + TILE - 1) / TILE, (m + TILE - 1) / TILE);
     if (p.D <= GPMI_MAXD) grid = dim3((n + SE_TR - 1) / SE_TR, (m + SE_TC - 1) / SE_TC);  // k_se_cov<>
-    extern int g_se_nt;
-    const int vec = vec_ok(dK, ldk) ? (g_se_nt ? 3 : 1) : 0;  // bit 1: non-temporal stores in k_se_cov<>
+    const int vec = vec_ok(dK, ldk) ? (c->tune.se_nt ? 3 : 1) : 0;  // bit 1: non-temporal stores in k_se_cov<>
     switch (p.D) {
     case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
     case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;

@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define GPMI_VERSION 100
+#define GPMI_VERSION 200
+
+/* the ABI: the ONLY symbols libgpmi.so exports (it is built with -fvisibility=hidden) */
+#define GPMI_API __attribute__((visibility("default")))
 
 typedef struct gpmi_ctx gpmi_ctx;
 typedef struct gpmi_seq gpmi_seq; /* sequential conditional sampler (gpmi_seq_*) */
@@ -67,21 +70,24 @@ enum {
 };
 
 /* ---- library / context ------------------------------------------------ */
-int gpmi_version(void);
-const char *gpmi_last_error(void);
-int gpmi_device_count(int *count);
-int gpmi_create(gpmi_ctx **ctx, int device);
-int gpmi_destroy(gpmi_ctx *ctx);
+GPMI_API int gpmi_version(void);
+GPMI_API const char *gpmi_last_error(void);
+GPMI_API int gpmi_device_count(int *count);
+GPMI_API int gpmi_create(gpmi_ctx **ctx, int device);
+GPMI_API int gpmi_destroy(gpmi_ctx *ctx);
 /* run on a caller-owned hipStream_t; NULL (handle 0) is HIP's legacy null stream -- what
  * torch's default stream is -- so `_dev` calls are ordered with the caller's other work there */
-int gpmi_set_stream(gpmi_ctx *ctx, void *hip_stream);
+GPMI_API int gpmi_set_stream(gpmi_ctx *ctx, void *hip_stream);
 /* back to the context's own (non-blocking) stream */
-int gpmi_reset_stream(gpmi_ctx *ctx);
-int gpmi_sync(gpmi_ctx *ctx);
+GPMI_API int gpmi_reset_stream(gpmi_ctx *ctx);
+GPMI_API int gpmi_sync(gpmi_ctx *ctx);
 /* pre-size the factorisation workspace for matrices of order <= n_max */
-int gpmi_reserve(gpmi_ctx *ctx, int n_max);
-/* tuning knobs (0 keeps the default): outer panel width (multiple of 128) */
-int gpmi_set_option(gpmi_ctx *ctx, const char *name, int value);
+GPMI_API int gpmi_reserve(gpmi_ctx *ctx, int n_max);
+/* algorithm switches of THIS context (never process-global): "nb_outer" (outer panel width, multiple
+ * of 128, 0 = auto), "grid_lanes", "lookahead", "fuse_diag", "ksplit", "block_recursive", "diag_waves",
+ * "syrk_order", "stagger", "se_nt", "nb_adapt", "calibrate", "timing", "kernel_timing"; unknown
+ * names return GPMI_EARG */
+GPMI_API int gpmi_set_option(gpmi_ctx *ctx, const char *name, int value);
 
 /* ---- covariance builders ---------------------------------------------- */
 
@@ -91,29 +97,29 @@ int gpmi_set_option(gpmi_ctx *ctx, const char *name, int value);
  * (D = 1), Stan cov_exp_quad models/fit_hyperparameters.stan:19 and the
  * diagonal update :21-24 / models/exact_gp.stan:20-22 (diag_add).
  * Y == NULL means Y = X (symmetric; enables GPMI_LOWER). */
-int gpmi_se_cov(gpmi_ctx *ctx, const double *X, int n, int ldx, const double *Y, int m, int ldy,
+GPMI_API int gpmi_se_cov(gpmi_ctx *ctx, const double *X, int n, int ldx, const double *Y, int m, int ldy,
                 int D, double alpha, const double *ell, int n_ell, double diag_add, int flags,
                 double *K, int ldk);
-int gpmi_se_cov_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, const double *dY, int m,
+GPMI_API int gpmi_se_cov_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, const double *dY, int m,
                     int ldy, int D, double alpha, const double *ell, int n_ell, double diag_add,
                     int flags, double *dK, int ldk);
 
 /* K[i,j] = alpha^2 * kind(x[i], y[j], l), 1-D inputs.  Replaces the matrix API
  * QQ/QR/RR(x,y,phi) of R/kernels.R:22-32 (GPMI_COMPAT_RR for :31 as written)
  * and a^2 * outer(ti, ti, FUN = kern) of pendulum_fit.R:237-240. */
-int gpmi_deriv_cov(gpmi_ctx *ctx, int kind, const double *x, int n, const double *y, int m,
+GPMI_API int gpmi_deriv_cov(gpmi_ctx *ctx, int kind, const double *x, int n, const double *y, int m,
                    double alpha, double l, int flags, double *K, int ldk);
-int gpmi_deriv_cov_dev(gpmi_ctx *ctx, int kind, const double *dx, int n, const double *dy, int m,
+GPMI_API int gpmi_deriv_cov_dev(gpmi_ctx *ctx, int kind, const double *dx, int n, const double *dy, int m,
                        double alpha, double l, int flags, double *dK, int ldk);
 
 /* out[i] = kind(tj[i], tk[i], l): the vectorised elementwise functions
  * QQ..TT(tj,tk,l) of derivative_kernels.R:39-73 (unit amplitude). */
-int gpmi_deriv_elem(gpmi_ctx *ctx, int kind, const double *tj, const double *tk, size_t len,
+GPMI_API int gpmi_deriv_elem(gpmi_ctx *ctx, int kind, const double *tj, const double *tk, size_t len,
                     double l, double *out);
 
 /* Joint [values; derivatives] covariance of order 2n,
  * [[QQ + sigma^2 I, QR], [RQ, RR]] + jitter I   (R/ode_gp_library.R:29-30). */
-int gpmi_joint_cov(gpmi_ctx *ctx, const double *t, int n, double alpha, double l, double sigma,
+GPMI_API int gpmi_joint_cov(gpmi_ctx *ctx, const double *t, int n, double alpha, double l, double sigma,
                    double jitter, int flags, double *K, int ldk);
 
 /* ---- dense factorisation ---------------------------------------------- */
@@ -121,13 +127,13 @@ int gpmi_joint_cov(gpmi_ctx *ctx, const double *t, int n, double alpha, double l
 /* In-place lower Cholesky A = L L^T (strict upper triangle zeroed on return,
  * like Stan's cholesky_decompose: models/fit_hyperparameters.stan:25,
  * models/exact_gp.stan:23; base-R chol() returns t(L)). */
-int gpmi_potrf(gpmi_ctx *ctx, double *A, int n, int lda);
-int gpmi_potrf_dev(gpmi_ctx *ctx, double *dA, int n, int lda, int *d_info);
+GPMI_API int gpmi_potrf(gpmi_ctx *ctx, double *A, int n, int lda);
+GPMI_API int gpmi_potrf_dev(gpmi_ctx *ctx, double *dA, int n, int lda, int *d_info);
 
 /* f = L z (models/exact_gp.stan:25) and z = L^-1 b (mdivide_left_tri_low inside
  * multi_normal_cholesky, models/fit_hyperparameters.stan:31). */
-int gpmi_trmv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *z, double *f);
-int gpmi_trsv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *b, double *z);
+GPMI_API int gpmi_trmv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *z, double *f);
+GPMI_API int gpmi_trsv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *b, double *z);
 
 /* ---- marginal likelihood ---------------------------------------------- */
 
@@ -135,11 +141,11 @@ int gpmi_trsv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double
  * Sigma = cov_exp_quad(X, alpha, rho) + (sigma^2 + jitter) I; L = chol(Sigma);
  * out[0] = -1/2 z'z - sum log L_ii - n/2 log(2 pi), out[1] = sum log L_ii,
  * out[2] = z'z, z = L^-1 y.  ell/n_ell as in gpmi_se_cov (rho == ell[0]). */
-int gpmi_logml(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+GPMI_API int gpmi_logml(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
                double alpha, const double *ell, int n_ell, double sigma, double jitter,
                double *out3);
 /* device-resident X, y; d_out3 (3 doubles) and d_info (1 int) in device memory */
-int gpmi_logml_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
+GPMI_API int gpmi_logml_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
                    double alpha, const double *ell, int n_ell, double sigma, double jitter,
                    double *d_out3, int *d_info);
 
@@ -148,7 +154,7 @@ int gpmi_logml_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const
  * autodiff computes per leapfrog step for models/fit_hyperparameters.stan:18-32 (the reference has
  * no function of its own for it); 1/2 tr((a a' - K^-1) dK/dtheta) with K^-1 formed on the device.
  * D <= 8.  Same status codes as gpmi_logml (k > 0: not positive definite, grad = NaN). */
-int gpmi_logml_grad(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+GPMI_API int gpmi_logml_grad(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
                     double alpha, const double *ell, int n_ell, double sigma, double jitter,
                     double *out3, double *grad);
 
@@ -157,25 +163,25 @@ int gpmi_logml_grad(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const
  * grid continues.  Replaces the stan()-fit + arg-max of R/tests.R:13-27 when a
  * grid search is acceptable; sharding over GPUs is done by the host layer
  * (one context per device / process). */
-int gpmi_logml_grid(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+GPMI_API int gpmi_logml_grid(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
                     const double *alpha, const double *rho, const double *sigma, int G,
                     double jitter, double *out3, int *info);
-int gpmi_logml_grid_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
+GPMI_API int gpmi_logml_grid_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
                         const double *alpha, const double *rho, const double *sigma, int G,
                         double jitter, double *d_out3, int *d_info);
 
 /* Log marginal likelihood of stacked observations yy = [y; y'] (length 2n)
  * under gpmi_joint_cov's matrix (BASELINE config c5). */
-int gpmi_joint_logml(gpmi_ctx *ctx, const double *t, int n, const double *yy, double alpha,
+GPMI_API int gpmi_joint_logml(gpmi_ctx *ctx, const double *t, int n, const double *yy, double alpha,
                      double l, double sigma, double jitter, double *out3);
-int gpmi_joint_logml_dev(gpmi_ctx *ctx, const double *dt, int n, const double *dyy, double alpha,
+GPMI_API int gpmi_joint_logml_dev(gpmi_ctx *ctx, const double *dt, int n, const double *dyy, double alpha,
                          double l, double sigma, double jitter, double *d_out3, int *d_info);
 
 /* ---- Rcpp export ------------------------------------------------------ */
 
 /* rbf_cov_chol(x1, l): Sigma_ij = exp(-(xi-xj)^2/(2 l^2)) + 1e-10 I, L = chol,
  * dLdl = dL/dl (forward-mode tangent).  covariance.cpp:9-47.  L, dLdl n x n. */
-int gpmi_rbf_cov_chol(gpmi_ctx *ctx, const double *x, int n, double l, double *L, int ldl,
+GPMI_API int gpmi_rbf_cov_chol(gpmi_ctx *ctx, const double *x, int n, double l, double *L, int ldl,
                       double *dLdl, int lddl);
 
 /* ---- Cholesky-factor interpolation over the length-scale ---------------
@@ -189,13 +195,13 @@ int gpmi_rbf_cov_chol(gpmi_ctx *ctx, const double *x, int n, double l, double *L
  *   gpmi_approx_L     : covariance.cpp:49-96 (lower triangle blended, zeros above)
  *   gpmi_approx_Lz    : models/cubic_interpolated_gp.hpp:38-73, f = approx_L(l) z, fused (the
  *                       blended matrix is never stored: 4 n^2/2 doubles read per call)      */
-int gpmi_interp_build(gpmi_ctx *ctx, const double *x, int n, const double *lp, int P);
-int gpmi_interp_load(gpmi_ctx *ctx, const double *lp, int P, const double *Ls, const double *dLdls,
+GPMI_API int gpmi_interp_build(gpmi_ctx *ctx, const double *x, int n, const double *lp, int P);
+GPMI_API int gpmi_interp_load(gpmi_ctx *ctx, const double *lp, int P, const double *Ls, const double *dLdls,
                      int n, int ld);
-int gpmi_approx_L(gpmi_ctx *ctx, double l, double *out, int ldo);
-int gpmi_approx_Lz(gpmi_ctx *ctx, double l, const double *z, double *f);
-int gpmi_approx_Lz_dev(gpmi_ctx *ctx, double l, const double *dz, double *df);
-int gpmi_interp_free(gpmi_ctx *ctx);
+GPMI_API int gpmi_approx_L(gpmi_ctx *ctx, double l, double *out, int ldo);
+GPMI_API int gpmi_approx_Lz(gpmi_ctx *ctx, double l, const double *z, double *f);
+GPMI_API int gpmi_approx_Lz_dev(gpmi_ctx *ctx, double l, const double *dz, double *df);
+GPMI_API int gpmi_interp_free(gpmi_ctx *ctx);
 
 /* ---- GP posterior (value / derivative) -------------------------------- */
 
@@ -207,7 +213,7 @@ int gpmi_interp_free(gpmi_ctx *ctx);
  *  sample_derivs moments pendulum_fit.R:242-251 : (QQ, RQ, RR), jitter 1e-8
  *  lorenz.Rmd:80-107 variant: separate prediction times ts.
  * mn: m doubles; Kn: m x m (symmetric, both triangles written). */
-int gpmi_gp_condition(gpmi_ctx *ctx, const double *t, int n, const double *ts, int m,
+GPMI_API int gpmi_gp_condition(gpmi_ctx *ctx, const double *t, int n, const double *ts, int m,
                       const double *y, double alpha, double l, double s2, double jitter,
                       int kindK, int kindS, int kindSS, int flags, double *mn, double *Kn, int ldkn);
 
@@ -226,38 +232,44 @@ int gpmi_gp_condition(gpmi_ctx *ctx, const double *t, int n, const double *ts, i
  * step.  The O(n^3) work (one Cholesky, two n-row triangular solves) happens once in
  * gpmi_seq_create; a step reads 12 n^2 B (factor + one n x n matrix).  max_steps <= 2048.
  * Status k > 0: K~ (create) or the star covariance (step, k = its order) is not positive definite. */
-int gpmi_seq_create(gpmi_ctx *ctx, gpmi_seq **out, const double *X, int n, int ldx, int D,
+GPMI_API int gpmi_seq_create(gpmi_ctx *ctx, gpmi_seq **out, const double *X, int n, int ldx, int D,
                     const double *mn, const double *Kn, int ldkn, double alpha, const double *ell,
                     int n_ell, double jitter, int max_steps);
-int gpmi_seq_step(gpmi_seq *seq, const double *xs /* D */, double *out2);
-int gpmi_seq_commit(gpmi_seq *seq, double dot_xs);
-int gpmi_seq_count(const gpmi_seq *seq); /* committed draws */
-int gpmi_seq_destroy(gpmi_seq *seq);
+GPMI_API int gpmi_seq_step(gpmi_seq *seq, const double *xs /* D */, double *out2);
+GPMI_API int gpmi_seq_commit(gpmi_seq *seq, double dot_xs);
+GPMI_API int gpmi_seq_count(const gpmi_seq *seq); /* committed draws */
+GPMI_API int gpmi_seq_destroy(gpmi_seq *seq);
 
 /* ---- diagnostics (tests / bench) -------------------------------------- */
 
 /* Elapsed ms of the most recent evaluation's stages, measured with HIP events
  * on the context's stream when timing is enabled via gpmi_set_option("timing",1):
  * ms[0] covariance build, ms[1] Cholesky, ms[2] finalize; n_launch[0..2]. */
-int gpmi_last_timing(gpmi_ctx *ctx, double *ms3);
+GPMI_API int gpmi_last_timing(gpmi_ctx *ctx, double *ms3);
 
 /* Per-kernel HIP-event timing, enabled with gpmi_set_option("kernel_timing", 1): event
  * pairs bracket every covariance-build launch (category 0; work = bytes written), every
  * trailing-update SYRK launch (1; work = algorithmic flops) on the context's stream.
  * out9[3*cat + 0..2] = launches, total ms, total work since the last reset. */
-int gpmi_kernel_timing(gpmi_ctx *ctx, int reset, double *out9);
+GPMI_API int gpmi_kernel_timing(gpmi_ctx *ctx, int reset, double *out9);
 
+/* ---- probes: tools/ only ------------------------------------------------
+ * Built into libgpmi_probes.so (-DGPMI_PROBES: `python -m gp_amd._build --probes`), never into the
+ * shipped libgpmi.so: micro-benchmarks, the A/B kernel variants and their option names
+ * (gemm_variant, syrk_persist, rect_auto, debug_topology). */
+#ifdef GPMI_PROBES
 /* Stand-alone trailing-update (SYRK, lower) launch on synthetic data, C(m x m) -= P P^T with
  * P m x k: average ms per launch over `reps` back-to-back launches (HIP events). */
-int gpmi_probe_syrk(gpmi_ctx *ctx, int m, int k, int reps, double *ms);
+GPMI_API int gpmi_probe_syrk(gpmi_ctx *ctx, int m, int k, int reps, double *ms);
 
 /* MFMA f64 fragment-layout probe: D = A(16x4) * B(4x16) on one wave with the
  * library's fragment conventions; out256 row-major D[i][j].  Host buffers. */
-int gpmi_probe_mfma(gpmi_ctx *ctx, const double *A64, const double *B64, double *out256);
+GPMI_API int gpmi_probe_mfma(gpmi_ctx *ctx, const double *A64, const double *B64, double *out256);
 /* Back-to-back v_mfma_f64_16x16x4_f64 issue-rate microbenchmark: achieved TFLOP/s over
  * the whole chip and (nullable) the shader clock held meanwhile, from
  * d(s_memtime)/d(s_memrealtime). */
-int gpmi_probe_mfma_peak(gpmi_ctx *ctx, int iters, double *tflops, double *clock_mhz);
+GPMI_API int gpmi_probe_mfma_peak(gpmi_ctx *ctx, int iters, double *tflops, double *clock_mhz);
+#endif /* GPMI_PROBES */
 
 #ifdef __cplusplus
 }

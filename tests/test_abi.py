@@ -10,9 +10,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
+def _header_functions(probes=False):
     src = open(os.path.join(ROOT, "include", "gpmi.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    m = re.search(r"#ifdef GPMI_PROBES(.*?)#endif", src, flags=re.S)
+    assert m, "probe section not found"
+    if probes:
+        src = m.group(1)
+    else:
+        src = src.replace(m.group(0), "")
     return sorted(set(re.findall(r"\b(gpmi_[A-Za-z0-9_]+)\s*\(", src)))
 
 
@@ -26,11 +32,26 @@ def test_build_and_exports():
     assert declared, "header parse found nothing"
     missing = [f for f in declared if f not in exported]
     assert not missing, missing
+    # ... and nothing else: no probe entry point, no internal launcher (-fvisibility=hidden)
+    assert sorted(exported) == declared, sorted(exported ^ set(declared))
+    assert not re.findall(r" T (launch_|_Z\w*launch_|_Z\w*gemm8|_Z\w*gemm9|_Z\w*syrk_persist)", out)
     assert sorted(_lib.SYMBOLS) == declared  # python binding covers the whole header
     h = _lib.load()
-    assert h.gpmi_version() == 100
+    assert h.gpmi_version() == 200
     # gfx950 code object is embedded
     assert b"gfx950" in open(lib, "rb").read()
+
+
+def test_probe_build_is_a_separate_library():
+    # tools/ run on libgpmi_probes.so (-DGPMI_PROBES): the product ABI plus the gpmi_probe_* entry points
+    from gp_amd import _build, _lib
+    lib = _build.build(probes=True)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib]).decode()
+    exported = set(re.findall(r" T (gpmi_[A-Za-z0-9_]+)", out))
+    assert sorted(exported) == sorted(_header_functions() + _header_functions(probes=True))
+    assert sorted(_lib.PROBE_SYMBOLS) == _header_functions(probes=True)
+    code = open(lib, "rb").read()
+    assert b"k_gemm9" in code and b"k_gemm9" not in open(_build.LIB, "rb").read()
 
 
 def test_signatures_are_plain_c():

@@ -113,15 +113,33 @@ def test_options_do_not_change_results_beyond_rounding(ctx, orc):
     X, y = orc.synth(900, 3)
     base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     vals = []
-    for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("lookahead", 1), ("lookahead", 0), ("gemm_variant", 0),
-                   ("gemm_variant", 1), ("gemm_variant", 2), ("syrk_order", 1), ("syrk_persist", 1), ("syrk_persist", 2), ("diag_waves", 4)):
+    for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("lookahead", 1), ("lookahead", 0), ("syrk_order", 1),
+                   ("diag_waves", 4), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 1)):
         ctx.set_option(opt, v)
         try:
             vals.append(ctx.logml(X, y, 1.0, [0.3], 0.1)[0])
         finally:
-            ctx.set_option("nb_outer", 0); ctx.set_option("lookahead", -1)
-            ctx.set_option("gemm_variant", 3); ctx.set_option("syrk_order", 0); ctx.set_option("syrk_persist", 0); ctx.set_option("diag_waves", 5)
+            ctx.set_option("nb_outer", 0); ctx.set_option("lookahead", -1); ctx.set_option("syrk_order", 0)
+            ctx.set_option("diag_waves", 5); ctx.set_option("ksplit", 1); ctx.set_option("stagger", (2 << 16) | 4)
+            ctx.set_option("se_nt", 1); ctx.set_option("nb_adapt", 0)
     assert all(abs(v - base) <= 1e-10 * abs(base) for v in vals), (base, vals)
+
+
+def test_options_are_per_context(ctx, orc):
+    # tuning lives in the context: a second context keeps its defaults while the first one is re-tuned
+    import gp_amd
+    X, y = orc.synth(700, 2)
+    other = gp_amd.Context(0)
+    try:
+        ctx.set_option("nb_outer", 128); ctx.set_option("fuse_diag", 0); ctx.set_option("block_recursive", 0)
+        a = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+        b = other.logml(X, y, 1.0, [0.3], 0.1)[0]
+    finally:
+        ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 7); ctx.set_option("block_recursive", 1)
+    c = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+    other.close()
+    assert b == c                       # `other` ran the default algorithm, bit for bit
+    assert abs(a - c) <= 1e-10 * abs(c)  # the re-tuned one is a re-ordering of the same sums
 
 
 def test_grid_lanes_match_single_evaluations(ctx, orc):

@@ -17,13 +17,40 @@ def test_library_loaded_and_device_is_gfx950(ctx):
     assert gp_amd.device_count() >= 1
 
 
-def test_mfma_f64_fragment_layout(ctx):
-    # D = A B with ASYMMETRIC integer operands: catches swapped row/col maps exactly
-    rng = np.random.default_rng(0)
-    A = rng.integers(-8, 9, size=(16, 4)).astype(float)
-    B = rng.integers(-8, 9, size=(4, 16)).astype(float) + np.arange(16)[None, :] * 3
-    D = ctx.probe_mfma(A, B)
-    np.testing.assert_array_equal(D, A @ B)
+_PROBE_SCRIPT = r"""
+import numpy as np, gp_amd
+from gp_amd.synth import synth
+ctx = gp_amd.Context(0)
+# D = A B with ASYMMETRIC integer operands: catches swapped row/col maps exactly
+rng = np.random.default_rng(0)
+A = rng.integers(-8, 9, size=(16, 4)).astype(float)
+B = rng.integers(-8, 9, size=(4, 16)).astype(float) + np.arange(16)[None, :] * 3
+assert np.array_equal(ctx.probe_mfma(A, B), A @ B)
+# the A/B kernel variants are re-orderings of the same factorisation
+X, y = synth(900, 3)
+base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+for opt, v, back in (("gemm_variant", 0, 3), ("gemm_variant", 1, 3), ("gemm_variant", 2, 3), ("syrk_persist", 1, 0), ("syrk_persist", 2, 0)):
+    ctx.set_option(opt, v)
+    got = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+    ctx.set_option(opt, back)
+    assert abs(got - base) <= 1e-10 * abs(base), (opt, v, got, base)
+print("probe build ok", base)
+"""
+
+
+def test_probe_build_fragment_layout_and_variants(ctx):
+    # the probe library (tools/ only) in a process of its own: MFMA f64 fragment layout and the A/B kernels
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPMI_USE_PROBES="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _PROBE_SCRIPT], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0 and "probe build ok" in r.stdout, r.stdout + r.stderr
+    # ... and the product library has neither the entry points nor the option names
+    import gp_amd
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.probe_mfma(np.zeros((16, 4)), np.zeros((4, 16)))
+    with pytest.raises(gp_amd.GpmiError):
+        ctx.set_option("gemm_variant", 1)
 
 
 @pytest.mark.parametrize("n,m,D", [(1, 1, 1), (21, 21, 1), (64, 64, 3), (65, 130, 3), (200, 77, 2), (257, 300, 5), (130, 129, 8), (70, 33, 9), (40, 50, 20)])

@@ -4,6 +4,7 @@ groups.   python tools/ab_bench.py "nb_adapt:0" "nb_adapt:1" [ns=4096,8192,16384
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 from gp_amd.synth import synth
 groups = [a for a in sys.argv[1:] if "=" not in a] or ["none:0"]

@@ -2,6 +2,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 from gp_amd.synth import synth
 ctx = gp_amd.Context(0)

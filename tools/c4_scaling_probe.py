@@ -3,6 +3,7 @@ vs the 8-point share one rank of an 8-GPU job gets (same call, no communication)
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 from gp_amd.synth import synth
 n = 8192

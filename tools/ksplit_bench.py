@@ -1,6 +1,7 @@
 """SYRK launch time with and without the K-split of tail-round tiles (option ksplit)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 ctx = gp_amd.Context(0)
 ctx.set_option("stagger", (2 << 16) | 4)

@@ -1,6 +1,7 @@
 import os, sys, time, itertools
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 from gp_amd.synth import synth
 opts = {"n": "16384", "G": "12", "lanes": "4", "nbo": "512", "order": "0", "stg": "131076", "la": "0", "res": "8", "lanela": "0", "reserve": "0"}

@@ -1,6 +1,7 @@
 """Stand-alone SYRK (trailing update) sweep: variant x K x m."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 ctx = gp_amd.Context(0)
 ms = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["16128", "8192", "4096"])]
