@@ -23,7 +23,7 @@ SYMBOLS = (
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
-    "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev",
+    "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
     "gpmi_interp_free", "gpmi_logml_grad",
     "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
     "gpmi_last_timing", "gpmi_kernel_timing",
@@ -327,6 +327,19 @@ class Context:
         f = np.empty(z.size)
         _chk(self._lib.gpmi_approx_Lz(self._h, _d(l), _p(z), _p(f)))
         return f
+
+    def approx_Lz_grad(self, l, z):
+        """(f, dfdl): approx_L(l) z and its partial in l (the `var` overload of build_output,
+        models/cubic_interpolated_gp.hpp:6-32)."""
+        z = _vec(z)
+        if z.size != getattr(self, "_itp_n", -1):
+            raise GpmiError(-1, "z must have the table's order")
+        f = np.empty(z.size); g = np.empty(z.size)
+        _chk(self._lib.gpmi_approx_Lz_grad(self._h, _d(l), _p(z), _p(f), _p(g)))
+        return f, g
+
+    def approx_Lz_grad_dev(self, l, dz_ptr, df_ptr, dg_ptr):
+        _chk(self._lib.gpmi_approx_Lz_grad_dev(self._h, _d(l), C.c_void_p(dz_ptr), C.c_void_p(df_ptr), C.c_void_p(dg_ptr)))
 
     def approx_Lz_dev(self, l, dz_ptr, df_ptr):
         _chk(self._lib.gpmi_approx_Lz_dev(self._h, _d(l), C.c_void_p(dz_ptr), C.c_void_p(df_ptr)))

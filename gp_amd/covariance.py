@@ -38,6 +38,15 @@ def approx_Lz(l, lp, Ls, dLdls, z, ctx=None):
     return c.approx_Lz(l, z)
 
 
+def approx_Lz_grad(l, lp, Ls, dLdls, z, ctx=None):
+    """(f, dfdl) of approx_Lz: the value and the partial with respect to l that the `var` overload of
+    build_output attaches under Stan's reverse mode (models/cubic_interpolated_gp.hpp:6-32, dvdl :67)."""
+    c = ctx or default_context()
+    k = _neighbours(l, lp)
+    c.interp_load([lp[k], lp[k + 1]], [Ls[k], Ls[k + 1]], [dLdls[k], dLdls[k + 1]])
+    return c.approx_Lz_grad(l, z)
+
+
 class FactorInterpolator:
     """Device-resident table for repeated queries: what test_interpolate.R:9-19 builds with P calls of
     rbf_cov_chol and cubic_interpolated_gp.stan consumes once per leapfrog step."""
@@ -52,3 +61,6 @@ class FactorInterpolator:
 
     def Lz(self, l, z):
         return self.ctx.approx_Lz(l, z)
+
+    def Lz_grad(self, l, z):
+        return self.ctx.approx_Lz_grad(l, z)

@@ -773,6 +773,65 @@ extern "C" int gpmi_trsv_lower(gpmi_ctx *c, const double *L, int n, int ldl, con
     return 0;
 }
 
+// ---- lanes: concurrent independent factorisations inside one GPU ---------------------------
+// Lane 0 is the context itself, lanes 1.. are internal contexts with their own workspaces.  Used
+// by the hyper-parameter grid and by the interpolation-table build (independent length-scales).
+static int lanes_prepare(gpmi_ctx *c, int lanes)
+{
+    for (int l = 1; l < lanes; ++l) {
+        if (!c->lane[l - 1]) {
+            int rc = gpmi_create(&c->lane[l - 1], c->device);
+            if (rc) return rc;
+        }
+        gpmi_ctx *lc = c->lane[l - 1];
+        lc->tune = c->tune;
+        lc->nb_outer = c->nb_outer;
+        lc->lookahead = c->lane_lookahead;  // default 0: concurrent lanes already fill the panel phases
+        if (c->lane_lookahead) {
+            int rc = ensure_aux_streams(lc);
+            if (rc) return rc;
+        }
+    }
+    if (lanes > 1 && c->lane_lookahead) {
+        int rc = ensure_aux_streams(c);
+        if (rc) return rc;
+    }
+    if (lanes > 1 && c->calibrate) {
+        int rc = calibrate_streams(c);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// lanes fork from / join into the caller's stream; with calibration every lane (lane 0 is this
+// context itself) runs on a stream of its own hardware pipe
+static void lanes_fork(gpmi_ctx *c, int lanes, hipStream_t caller)
+{
+    if (lanes <= 1) return;
+    c->lookahead = c->lane_lookahead;
+    const bool useq = c->calibrate && c->nq > 1;
+    hipEventRecord(c->evFork, caller);
+    for (int l = 0; l < lanes; ++l) {
+        gpmi_ctx *lc = l ? c->lane[l - 1] : c;
+        lc->stream = useq ? c->qstream[l % c->nq] : (l ? lc->own_stream : caller);
+        if (lc->stream != caller) hipStreamWaitEvent(lc->stream, c->evFork, 0);
+    }
+}
+
+static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
+{
+    if (lanes <= 1) return;
+    c->lookahead = la_saved;
+    for (int l = 0; l < lanes; ++l) {
+        gpmi_ctx *lc = l ? c->lane[l - 1] : c;
+        if (lc->stream != caller) {
+            hipEventRecord(lc->evJoin, lc->stream);
+            hipStreamWaitEvent(caller, lc->evJoin, 0);
+        }
+        lc->stream = l ? lc->own_stream : caller;
+    }
+}
+
 // ---- marginal likelihood -----------------------------------------------------
 static int logml_core(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dy, const SeParams &p,
                       double diag_add, double *d_out3, int *d_info)
@@ -824,60 +883,18 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
     int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : (G % 5 == 0 ? 5 : 4)));
     if (lanes > 8) lanes = 8;
     if (lanes > G) lanes = G;
-    for (int l = 1; l < lanes; ++l) {
-        if (!c->lane[l - 1]) {
-            int rc = gpmi_create(&c->lane[l - 1], c->device);
-            if (rc) return rc;
-        }
-        gpmi_ctx *lc = c->lane[l - 1];
-        lc->tune = c->tune;
-        lc->nb_outer = c->nb_outer;
-        lc->lookahead = c->lane_lookahead;  // default 0: concurrent lanes already fill the panel phases
-        if (c->lane_lookahead) {
-            int rc = ensure_aux_streams(lc);
-            if (rc) return rc;
-        }
-    }
-    if (lanes > 1 && c->lane_lookahead) {
-        int rc = ensure_aux_streams(c);
-        if (rc) return rc;
-    }
-    if (lanes > 1 && c->calibrate) {
-        int rc = calibrate_streams(c);
-        if (rc) return rc;
-    }
+    int rc = lanes_prepare(c, lanes);
+    if (rc) return rc;
     const int la_saved = c->lookahead;
     hipStream_t const caller = c->stream;
-    if (lanes > 1) {
-        // lanes fork from / join into the caller's stream; with calibration every lane (lane 0
-        // is this context itself) runs on a stream of its own hardware pipe
-        c->lookahead = c->lane_lookahead;
-        const bool useq = c->calibrate && c->nq > 1;
-        hipEventRecord(c->evFork, caller);
-        for (int l = 0; l < lanes; ++l) {
-            gpmi_ctx *lc = l ? c->lane[l - 1] : c;
-            lc->stream = useq ? c->qstream[l % c->nq] : (l ? lc->own_stream : caller);
-            if (lc->stream != caller) hipStreamWaitEvent(lc->stream, c->evFork, 0);
-        }
-    }
-    int rc = 0;
+    lanes_fork(c, lanes, caller);
     for (int g = 0; g < G && !rc; ++g) {
         SeParams p;
         rc = fill_params(&p, D, alpha[g], &rho[g], 1);
         gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
         if (!rc) rc = logml_core(lc, dX, n, ldx, dy, p, sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g);
     }
-    c->lookahead = la_saved;
-    if (lanes > 1) {
-        for (int l = 0; l < lanes; ++l) {
-            gpmi_ctx *lc = l ? c->lane[l - 1] : c;
-            if (lc->stream != caller) {
-                hipEventRecord(lc->evJoin, lc->stream);
-                hipStreamWaitEvent(caller, lc->evJoin, 0);
-            }
-            lc->stream = l ? lc->own_stream : caller;
-        }
-    }
+    lanes_join(c, lanes, caller, la_saved);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     return 0;
@@ -997,6 +1014,20 @@ __global__ void k_rbf_dsigma(const double *__restrict__ x, int n, double l, doub
 }
 }  // namespace
 
+// every buffer rbf_cov_chol_core(c, ., n, ...) uses, at its final size
+static int rbf_cov_chol_reserve(gpmi_ctx *c, int n)
+{
+    int rc;
+    if ((rc = reserve_ws(c, n, n))) return rc;
+    const int ldd = ((n + 15) / 16) * 16 + 16;
+    const size_t msz = (size_t)ldd * (n + 1) * sizeof(double);
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    double *b;
+    for (int slot = 1; slot <= 3; ++slot)
+        if ((rc = stage_buf(c, slot, msz, &b))) return rc;
+    return scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &b);
+}
+
 // device core: x resident in dx; on return (stream order) Lc holds L (zero upper) and S holds dL/dl,
 // both n x n with leading dimension ldd in the context's staging buffers 3 and 1
 static int rbf_cov_chol_core(gpmi_ctx *c, const double *dx, int n, double l, double **Lc_out, double **S_out, int *ldd_out)
@@ -1079,7 +1110,7 @@ static int interp_alloc(gpmi_ctx *c, const double *lp, int P, int n)
     c->itp_ld = (size_t)((n + 1) & ~1);
     const size_t bytes = (size_t)P * c->itp_ld * n * sizeof(double);
     if (hipMalloc((void **)&c->itp_L, bytes) != hipSuccess || hipMalloc((void **)&c->itp_dL, bytes) != hipSuccess ||
-        hipMalloc((void **)&c->itp_part, (size_t)hermite_mv_chunks(n) * n * sizeof(double)) != hipSuccess) {
+        hipMalloc((void **)&c->itp_part, 2 * (size_t)hermite_mv_chunks(n) * n * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError();
         gpmi_interp_free(c);
         return gpmi_fail(GPMI_ENOMEM, "interpolation table of %d x %d x %d does not fit", P, n, n);
@@ -1098,24 +1129,50 @@ extern "C" int gpmi_interp_build(gpmi_ctx *c, const double *x, int n, const doub
     if (!x) return gpmi_fail(GPMI_EARG, "bad argument");
     int rc;
     if ((rc = interp_alloc(c, lp, P, n))) return rc;
-    double *dx;
-    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
-    hipStream_t s = c->stream;
-    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-    int first_bad = 0;
-    for (int p = 0; p < P; ++p) {
+    for (int p = 0; p < P; ++p)
         if (!(lp[p] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scales must be positive");
+    double *dx;
+    int *dinfo;
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double) + (size_t)P * sizeof(int) + 64, &dx))) return rc;
+    dinfo = (int *)(dx + n + 1);
+    // The P table entries (test_interpolate.R:9-19: P calls of rbf_cov_chol; interpolated_gp.stan:10-28)
+    // are independent factorisations: they run on the grid lanes, entry p on lane p mod lanes, every
+    // lane in its own workspace and staging buffers, and nothing synchronises with the host until
+    // all are enqueued.
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
+    if (lanes > 8) lanes = 8;
+    if (lanes > P) lanes = P;
+    if ((rc = lanes_prepare(c, lanes))) return rc;
+    // buffers every lane needs, sized BEFORE the fork (a growing buffer synchronises its stream)
+    for (int l = 0; l < lanes; ++l) {
+        gpmi_ctx *lc = l ? c->lane[l - 1] : c;
+        if ((rc = rbf_cov_chol_reserve(lc, n))) return rc;
+    }
+    const int la_saved = c->lookahead;
+    hipStream_t const caller = c->stream;
+    HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, caller));
+    lanes_fork(c, lanes, caller);
+    for (int p = 0; p < P && !rc; ++p) {
+        gpmi_ctx *lc = (p % lanes == 0) ? c : c->lane[p % lanes - 1];
         double *Lc, *S;
         int ldd;
-        if ((rc = rbf_cov_chol_core(c, dx, n, lp[p], &Lc, &S, &ldd))) return rc;
+        rc = rbf_cov_chol_core(lc, dx, n, lp[p], &Lc, &S, &ldd);
+        if (rc) break;
+        hipStream_t s = lc->stream;
         launch_copy_matrix(s, Lc, (size_t)ldd, c->itp_L + (size_t)p * c->itp_ld * n, c->itp_ld, n, n, 0);
         launch_copy_matrix(s, S, (size_t)ldd, c->itp_dL + (size_t)p * c->itp_ld * n, c->itp_ld, n, n, 0);
-        int info = 0;
-        HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (info && !first_bad) first_bad = info;
+        if (hipMemcpyAsync(dinfo + p, lc->d_info, sizeof(int), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            rc = gpmi_fail(GPMI_EHIP, "info copy failed");
     }
-    return first_bad;
+    lanes_join(c, lanes, caller, la_saved);
+    if (rc) return rc;
+    std::vector<int> info(P, 0);
+    HIPCHK(hipMemcpyAsync(info.data(), dinfo, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, caller));
+    HIPCHK(hipStreamSynchronize(caller));
+    HIPCHK(hipGetLastError());
+    for (int p = 0; p < P; ++p)
+        if (info[p]) return info[p];
+    return 0;
 }
 
 extern "C" int gpmi_interp_load(gpmi_ctx *c, const double *lp, int P, const double *Ls, const double *dLdls,
@@ -1165,35 +1222,60 @@ extern "C" int gpmi_approx_L(gpmi_ctx *c, double l, double *out, int ldo)
     return 0;
 }
 
-extern "C" int gpmi_approx_Lz_dev(gpmi_ctx *c, double l, const double *dz, double *df)
+static int approx_Lz_core(gpmi_ctx *c, double l, const double *dz, double *df, double *ddfdl)
 {
-    ENTER(c);
     if (!c->itp_L) return gpmi_fail(GPMI_EARG, "no interpolation table (gpmi_interp_build / gpmi_interp_load first)");
     if (!dz || !df || !(l == l)) return gpmi_fail(GPMI_EARG, "bad argument");
     const int n = c->itp_n;
     const int k = interp_interval(c, l);
     const size_t msz = c->itp_ld * n;
-    HIPCHK(hipMemsetAsync(c->itp_part, 0, (size_t)hermite_mv_chunks(n) * n * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->itp_part, 0, (ddfdl ? 2 : 1) * (size_t)hermite_mv_chunks(n) * n * sizeof(double), c->stream));
     launch_hermite_mv(c->stream, c->itp_L + k * msz, c->itp_L + (k + 1) * msz, c->itp_dL + k * msz,
-                      c->itp_dL + (k + 1) * msz, c->itp_ld, n, c->itp_lp[k], c->itp_lp[k + 1], l, dz, c->itp_part, df);
+                      c->itp_dL + (k + 1) * msz, c->itp_ld, n, c->itp_lp[k], c->itp_lp[k + 1], l, dz, c->itp_part, df, ddfdl);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_approx_Lz_dev(gpmi_ctx *c, double l, const double *dz, double *df)
+{
+    ENTER(c);
+    return approx_Lz_core(c, l, dz, df, nullptr);
+}
+
+extern "C" int gpmi_approx_Lz_grad_dev(gpmi_ctx *c, double l, const double *dz, double *df, double *ddfdl)
+{
+    ENTER(c);
+    if (!ddfdl) return gpmi_fail(GPMI_EARG, "bad argument");
+    return approx_Lz_core(c, l, dz, df, ddfdl);
+}
+
+static int approx_Lz_host(gpmi_ctx *c, double l, const double *z, double *f, double *dfdl)
+{
+    if (!c->itp_L) return gpmi_fail(GPMI_EARG, "no interpolation table (gpmi_interp_build / gpmi_interp_load first)");
+    if (!z || !f) return gpmi_fail(GPMI_EARG, "bad argument");
+    const int n = c->itp_n;
+    int rc;
+    double *dz;
+    if ((rc = stage_buf(c, 0, 3 * (size_t)n * sizeof(double), &dz))) return rc;
+    HIPCHK(hipMemcpyAsync(dz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = approx_Lz_core(c, l, dz, dz + n, dfdl ? dz + 2 * (size_t)n : nullptr))) return rc;
+    HIPCHK(hipMemcpyAsync(f, dz + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (dfdl) HIPCHK(hipMemcpyAsync(dfdl, dz + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 extern "C" int gpmi_approx_Lz(gpmi_ctx *c, double l, const double *z, double *f)
 {
     ENTER(c);
-    if (!c->itp_L) return gpmi_fail(GPMI_EARG, "no interpolation table (gpmi_interp_build / gpmi_interp_load first)");
-    if (!z || !f) return gpmi_fail(GPMI_EARG, "bad argument");
-    const int n = c->itp_n;
-    int rc;
-    double *dz;
-    if ((rc = stage_buf(c, 0, 2 * (size_t)n * sizeof(double), &dz))) return rc;
-    HIPCHK(hipMemcpyAsync(dz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if ((rc = gpmi_approx_Lz_dev(c, l, dz, dz + n))) return rc;
-    HIPCHK(hipMemcpyAsync(f, dz + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    return approx_Lz_host(c, l, z, f, nullptr);
+}
+
+extern "C" int gpmi_approx_Lz_grad(gpmi_ctx *c, double l, const double *z, double *f, double *dfdl)
+{
+    ENTER(c);
+    if (!dfdl) return gpmi_fail(GPMI_EARG, "bad argument");
+    return approx_Lz_host(c, l, z, f, dfdl);
 }
 
 // ---- gradient of the log marginal likelihood ---------------------------

@@ -123,7 +123,8 @@ void launch_transpose(hipStream_t s, const double *src, size_t lds, double *dst,
 void launch_hermite_blend(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
                           size_t ld, int n, double x1, double x2, double l, double *out, size_t ldo);
 void launch_hermite_mv(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
-                       size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f);
+                       size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f,
+                       double *dfdl /* nullable: (dv/dl) z, the reverse-mode partial of approx_Lz */);
 int hermite_mv_chunks(int n);
 void launch_phi_mask(hipStream_t s, double *B, size_t ld, int n); // keep upper, halve diag, zero strict lower
 

@@ -354,11 +354,16 @@ __global__ __launch_bounds__(256) void k_hermite_blend(const double *__restrict_
 // f = blend(l) z without storing the blend: thread = row, blockIdx.y = chunk of HMV_CW columns;
 // partial row sums go to part[chunk][row] and are added in ascending chunk order by
 // k_hermite_mv_sum (fixed order: results do not depend on scheduling).
+// GRAD: the same pass also accumulates (dv/dl) z -- the partial Stan's reverse mode attaches to
+// approx_Lz (build_output's `var` overload, models/cubic_interpolated_gp.hpp:6-32; dvdl as written at
+// :67) -- into partg: no extra HBM traffic, the four triangles are read once.
 constexpr int HMV_CW = 128;
+template <bool GRAD>
 __global__ __launch_bounds__(256) void k_hermite_mv(const double *__restrict__ L1, const double *__restrict__ L2,
                                                     const double *__restrict__ D1, const double *__restrict__ D2,
-                                                    size_t ld, int n, double dx, double t,
-                                                    const double *__restrict__ z, double *__restrict__ part)
+                                                    size_t ld, int n, double dx, double t, double dtdl,
+                                                    const double *__restrict__ z, double *__restrict__ part,
+                                                    double *__restrict__ partg)
 {
     __shared__ double sz[HMV_CW];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -368,12 +373,19 @@ __global__ __launch_bounds__(256) void k_hermite_mv(const double *__restrict__ L
     __syncthreads();
     if (i >= n) return;
     const int jend = (i + 1 < j0 + HMV_CW) ? i + 1 : j0 + HMV_CW;  // columns j <= i
-    double acc = 0.0;
+    double acc = 0.0, accg = 0.0;
     for (int j = j0; j < jend; ++j) {
         const size_t o = (size_t)i + (size_t)j * ld;
-        acc += hermite(L1[o], L2[o], D1[o], D2[o], dx, t) * sz[j - j0];
+        const double y1 = L1[o], y2 = L2[o], k1 = D1[o], k2 = D2[o];
+        acc += hermite(y1, y2, k1, k2, dx, t) * sz[j - j0];
+        if constexpr (GRAD) {
+            const double a = k1 * dx - (y2 - y1);
+            const double b = -k2 * dx + (y2 - y1);
+            accg += ((b * (2 - 3 * t) * t + a * (1 + t * (-4 + 3 * t)) - y1 + y2) * dtdl) * sz[j - j0];
+        }
     }
     part[(size_t)blockIdx.y * n + i] = acc;
+    if constexpr (GRAD) partg[(size_t)blockIdx.y * n + i] = accg;
 }
 
 __global__ void k_hermite_mv_sum(const double *__restrict__ part, int n, int nchunks, double *__restrict__ f)
@@ -481,12 +493,21 @@ void launch_hermite_blend(hipStream_t s, const double *L1, const double *L2, con
 
 int hermite_mv_chunks(int n) { return (n + HMV_CW - 1) / HMV_CW; }
 
+// part: 2 * hermite_mv_chunks(n) * n doubles, pre-zeroed; dfdl == nullptr: value only
 void launch_hermite_mv(hipStream_t s, const double *L1, const double *L2, const double *D1, const double *D2,
-                       size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f)
+                       size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f,
+                       double *dfdl)
 {
     if (n <= 0) return;
     const double t = (l - x1) / (x2 - x1);
+    const double dtdl = 1 / (x2 - x1);
     const int nch = hermite_mv_chunks(n);
-    hipLaunchKernelGGL(k_hermite_mv, dim3((n + 255) / 256, nch), 256, 0, s, L1, L2, D1, D2, ld, n, x2 - x1, t, z, part);
+    double *partg = part + (size_t)nch * n;
+    const dim3 grid((n + 255) / 256, nch);
+    if (dfdl)
+        hipLaunchKernelGGL(k_hermite_mv<true>, grid, 256, 0, s, L1, L2, D1, D2, ld, n, x2 - x1, t, dtdl, z, part, partg);
+    else
+        hipLaunchKernelGGL(k_hermite_mv<false>, grid, 256, 0, s, L1, L2, D1, D2, ld, n, x2 - x1, t, dtdl, z, part, partg);
     hipLaunchKernelGGL(k_hermite_mv_sum, dim3((n + 255) / 256), 256, 0, s, part, n, nch, f);
+    if (dfdl) hipLaunchKernelGGL(k_hermite_mv_sum, dim3((n + 255) / 256), 256, 0, s, partg, n, nch, dfdl);
 }

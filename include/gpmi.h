@@ -194,13 +194,21 @@ GPMI_API int gpmi_rbf_cov_chol(gpmi_ctx *ctx, const double *x, int n, double l, 
  *                       models/cubic_interpolated_gp.stan:11-12
  *   gpmi_approx_L     : covariance.cpp:49-96 (lower triangle blended, zeros above)
  *   gpmi_approx_Lz    : models/cubic_interpolated_gp.hpp:38-73, f = approx_L(l) z, fused (the
- *                       blended matrix is never stored: 4 n^2/2 doubles read per call)      */
+ *                       blended matrix is never stored: 4 n^2/2 doubles read per call)
+ *   gpmi_approx_Lz_grad : the same value plus dfdl = (dv/dl) z, the partial Stan's reverse mode
+ *                       attaches to every output of approx_Lz (`var` overload of build_output,
+ *                       cubic_interpolated_gp.hpp:6-32, dvdl :67) -- what makes the external
+ *                       function differentiable in l (cubic_interpolated_gp.stan:1-3); same pass,
+ *                       same traffic.  (d f / d z is the blend itself: gpmi_approx_L.)
+ * gpmi_interp_build factors the P table entries concurrently on the context's grid lanes.      */
 GPMI_API int gpmi_interp_build(gpmi_ctx *ctx, const double *x, int n, const double *lp, int P);
 GPMI_API int gpmi_interp_load(gpmi_ctx *ctx, const double *lp, int P, const double *Ls, const double *dLdls,
                      int n, int ld);
 GPMI_API int gpmi_approx_L(gpmi_ctx *ctx, double l, double *out, int ldo);
 GPMI_API int gpmi_approx_Lz(gpmi_ctx *ctx, double l, const double *z, double *f);
 GPMI_API int gpmi_approx_Lz_dev(gpmi_ctx *ctx, double l, const double *dz, double *df);
+GPMI_API int gpmi_approx_Lz_grad(gpmi_ctx *ctx, double l, const double *z, double *f, double *dfdl);
+GPMI_API int gpmi_approx_Lz_grad_dev(gpmi_ctx *ctx, double l, const double *dz, double *df, double *ddfdl);
 GPMI_API int gpmi_interp_free(gpmi_ctx *ctx);
 
 /* ---- GP posterior (value / derivative) -------------------------------- */

@@ -524,7 +524,8 @@ void orc_approx_L(double l, const double *lp, int P, const double *Ls, const dou
 
 /* approx_Lz(l, lp, Ls, dLdls, z) = v z with v the same Hermite blend formed as full matrices
  * (the upper triangles of the factors are zero)        models/cubic_interpolated_gp.hpp:38-73
- * (build_output, :33-35, adds a zero vector) */
+ * (value only: what the `double` overload of build_output, :34-36, leaves; orc_approx_Lz_grad below
+ * restates the `var` overload's tangent) */
 void orc_approx_Lz(double l, const double *lp, int P, const double *Ls, const double *dLs,
                    int n, const double *z, double *f)
 {
@@ -536,6 +537,40 @@ void orc_approx_Lz(double l, const double *lp, int P, const double *Ls, const do
         f[i] = acc;
     }
     free(v);
+}
+
+/* approx_Lz under Stan's reverse mode: the `var` overload of build_output
+ * (models/cubic_interpolated_gp.hpp:6-32) attaches to output i the partial dfdl(i) = (dvdl z)(i) with
+ * respect to l (precomp_v_vari(0.0, l.vi_, dfdl(i))); the value stays v z (:72).  Only the `double`
+ * overload (:34-36) returns zeros.  dvdl as written at :67, dtdl = 1 / (x2 - x1) at :53; the
+ * matrices are formed in full (the factors' upper triangles are zero), as :59-67 do. */
+void orc_approx_Lz_grad(double l, const double *lp, int P, const double *Ls, const double *dLs,
+                        int n, const double *z, double *f, double *dfdl)
+{
+    int lidx = 0;
+    for (; lidx < P - 1; lidx++)
+        if (lp[lidx + 1] >= l) break;
+    if (lidx > P - 2) lidx = P - 2;
+    double x1 = lp[lidx], x2 = lp[lidx + 1];
+    double t = (l - x1) / (x2 - x1);
+    double dtdl = 1 / (x2 - x1);
+    const double *Y1 = Ls + (size_t)lidx * n * n, *Y2 = Ls + (size_t)(lidx + 1) * n * n;
+    const double *K1 = dLs + (size_t)lidx * n * n, *K2 = dLs + (size_t)(lidx + 1) * n * n;
+    for (int i = 0; i < n; ++i) {
+        double accv = 0.0, accd = 0.0;
+        for (int j = 0; j < n; ++j) {
+            double y1 = A_(Y1, n, i, j), y2 = A_(Y2, n, i, j);
+            double k1 = A_(K1, n, i, j), k2 = A_(K2, n, i, j);
+            double a = k1 * (x2 - x1) - (y2 - y1);
+            double b = -k2 * (x2 - x1) + (y2 - y1);
+            double v = (1 - t) * y1 + t * y2 + t * (1 - t) * (a * (1 - t) + b * t);
+            double dvdl = (b * (2 - 3 * t) * t + a * (1 + t * (-4 + 3 * t)) - y1 + y2) * dtdl;
+            accv += v * z[j];
+            accd += dvdl * z[j];
+        }
+        f[i] = accv;
+        dfdl[i] = accd;
+    }
 }
 
 /* ------------------------------------------------------------------ */

@@ -192,6 +192,29 @@ def approx_Lz(l, lp, Ls, dLs, z):
     return f
 
 
+def approx_Lz_grad(l, lp, Ls, dLs, z):
+    """(f, dfdl): value v z and the reverse-mode partial dvdl z of models/cubic_interpolated_gp.hpp:6-32,62-72."""
+    lp = np.ascontiguousarray(lp, dtype=np.float64); P = lp.size
+    n = Ls[0].shape[0]
+    Ls = np.ascontiguousarray(np.stack([np.asfortranarray(a).ravel(order="F") for a in Ls]))
+    dLs = np.ascontiguousarray(np.stack([np.asfortranarray(a).ravel(order="F") for a in dLs]))
+    z = np.ascontiguousarray(z, dtype=np.float64); f = np.empty(n); g = np.empty(n)
+    lib().orc_approx_Lz_grad(_d(l), _p(lp), P, _p(Ls), _p(dLs), n, _p(z), _p(f), _p(g))
+    return f, g
+
+
+def gp_condition(K, Ks, Kss, y, s2, jitter=0.0):
+    """(mn, Kn): mn = Ks solve(K + s2 I, y), Kn = Kss - Ks solve(K + s2 I, t(Ks)) + jitter I through the
+    oracle's LU (base-R solve() == dgesv): the generic form of R/ode_gp.R:1-32, pendulum_fit.R:242-251."""
+    K = _f(K); Ks = _f(Ks); Kss = _f(Kss); y = np.ascontiguousarray(y, dtype=np.float64)
+    n = K.shape[0]; m = Ks.shape[0]
+    mn = np.empty(m); Kn = np.empty((m, m), order="F")
+    info = lib().orc_gp_condition(_p(K), n, _p(Ks), m, _p(Kss), _p(y), _d(s2), _d(jitter), _p(mn), _p(Kn))
+    if info:
+        raise ValueError(info)
+    return mn, Kn
+
+
 def p_Xn(tn, Xn, alpha, l, sigma):
     tn = np.ascontiguousarray(tn, dtype=np.float64); Xn = np.ascontiguousarray(Xn, dtype=np.float64)
     n = tn.size; mn = np.empty(n); Kn = np.empty((n, n), order="F")

@@ -31,7 +31,7 @@ def ctx():
 def golden():
     import json
     g = {}
-    for name in ("gp_derivs", "kat"):
+    for name in ("gp_derivs", "kat", "ch2"):
         with open(os.path.join(ROOT, "tests", "golden", name + ".json")) as f:
             g[name] = json.load(f)
     return g

@@ -11,7 +11,13 @@ Two sources, both data only (no reference source text is stored):
    with runpy (it is a script, not a module): the nine kernels QQ..TT
    (gp_derivs.py:15-40) on a small (tj, tk, l, a) grid, and K / KsK / KsKs /
    mu / cov for its N = 25 pendulum data set (gp_derivs.py:59-113).
-2. kat.json -- closed-form known-answer tests for the marginal-likelihood path
+2. ch2.json -- outputs of the two GP cells of /root/reference/ch2.py (:16-43 and :58-85), each cell
+   executed in memory as the reference wrote it (Agg backend, seeded numpy.random): its own kernel
+   `makeK` (eta2 exp(-(x1-x2)^2 / l2): alpha^2 = eta2, rho^2 = l2 / 2) at N = 1000, the data block
+   Kdd, the posterior mean m = Ksd Kdd^-1 f (numpy.linalg.solve, i.e. LAPACK dgesv -- what base-R
+   solve() is) and strided samples of Kss and of the posterior covariance Kt.  An SE build at 40x
+   the gp_derivs.py size and a noise-free (sigma2 = 0) posterior.
+3. kat.json -- closed-form known-answer tests for the marginal-likelihood path
    (models/fit_hyperparameters.stan:18-32), computed with LAPACK (scipy
    dpotrf/dtrtrs) and confirmed with mpmath at 50 digits.  The reference has no
    executable Stan/R here, so these pin the oracle's restatement of that path
@@ -26,6 +32,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/gp_derivs.py"
+REF_CH2 = "/root/reference/ch2.py"
 
 
 def gen_gp_derivs():
@@ -76,6 +83,40 @@ def gen_gp_derivs():
     with open(os.path.join(HERE, "gp_derivs.json"), "w") as f:
         json.dump(out, f)
     print("wrote gp_derivs.json:", len(cases), "kernel cases; K[0,1] =", repr(out["posterior"]["K"][0][1]))
+
+
+def gen_ch2():
+    """The reference script is a sequence of `#%%` cells that re-bind the same names; each GP cell
+    is executed on its own (after the import cell) so that ITS values are the ones captured."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import matplotlib
+    matplotlib.use("Agg")
+    cells = open(REF_CH2).read().split("#%%")
+    gp_cells = [c for c in cells if "makeK" in c]
+    assert len(gp_cells) == 2, len(gp_cells)
+    out = {"source": "cells of /root/reference/ch2.py executed in memory (:16-43, :58-85); data only", "cells": []}
+    for cell in gp_cells:
+        ns = {}
+        exec(compile(cells[1], REF_CH2, "exec"), ns)      # the import cell
+        ns["numpy"].random.seed(1234)
+        exec(compile(cell, REF_CH2, "exec"), ns)
+        N = int(ns["N"])
+        ri = list(range(0, N, 37)); ci = list(range(0, N, 41))
+        Kss = np.asarray(ns["Kss"]); Kt = np.asarray(ns["Kt"])
+        out["cells"].append({
+            "N": N, "eta2": float(ns["eta2"]), "l2": float(ns["l2"]), "sigma2": float(ns["sigma2"]),
+            "xd": np.asarray(ns["xd"]).tolist(), "f": np.asarray(ns["f"]).tolist(),
+            "Kdd": np.asarray(ns["Kdd"]).tolist(),
+            "Ksd_rows": ri, "Ksd": np.asarray(ns["Ksd"])[ri, :].tolist(),
+            "m": np.asarray(ns["m"]).tolist(),
+            "rows": ri, "cols": ci,
+            "Kss_sample": Kss[np.ix_(ri, ci)].tolist(),
+            "Kt_sample": Kt[np.ix_(ri, ci)].tolist(),
+            "Kt_diag": np.diag(Kt).tolist(),
+        })
+        print("ch2 cell: N =", N, "eta2 =", ns["eta2"], "sigma2 =", ns["sigma2"], "m[500] =", repr(float(ns["m"][500])))
+    with open(os.path.join(HERE, "ch2.json"), "w") as f:
+        json.dump(out, f)
 
 
 def _logml_lapack(x, y, alpha, rho, sigma, jitter=0.0):
@@ -139,4 +180,5 @@ if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("reference not present; fixtures are committed, nothing to do")
     gen_gp_derivs()
+    gen_ch2()
     gen_kat()

@@ -84,3 +84,81 @@ def test_host_mirror_and_errors(ctx, orc):
         ctx.interp_load([0.8, 0.5], Ls[:2], dLs[:2])  # not increasing
     with pytest.raises(gp_amd.GpmiError):
         ctx.interp_build(x, [0.5, -1.0 + 0.5, 0.9])  # not increasing / non-positive
+
+
+def _reference_grid():
+    # test_interpolate.R:5-9: x = seq(0, 10, length = N), lp = seq(qgamma(.05, 4, 4), qgamma(.95, 4, 4), length = 10)
+    from scipy.stats import gamma
+    return np.linspace(gamma.ppf(0.05, 4.0, scale=0.25), gamma.ppf(0.95, 4.0, scale=0.25), 10)
+
+
+def test_approx_Lz_grad_vs_oracle_on_the_reference_grid(ctx, orc):
+    """dfdl = (dv/dl) z, the partial the `var` overload of build_output attaches to approx_Lz
+    (models/cubic_interpolated_gp.hpp:6-32, dvdl :67), on the P = 10 length-scale grid of
+    test_interpolate.R:9 -- against the oracle's restatement (pinned by central differences in
+    tests/test_oracle.py) and, directly, against central differences of the device's own value."""
+    lp = _reference_grid()
+    x = np.linspace(0.0, 10.0, 30)
+    Ls, dLs = _table(orc, x, lp)
+    ctx.interp_load(lp, Ls, dLs)
+    z = np.cos(0.7 * np.arange(30.0))
+    for l in (lp[0], 0.5 * (lp[0] + lp[1]), lp[3] + 0.3 * (lp[4] - lp[3]), lp[5], lp[8] + 0.9 * (lp[9] - lp[8]), lp[9], 0.2, 2.5):
+        f, g = ctx.approx_Lz_grad(l, z)
+        fo, go = orc.approx_Lz_grad(l, lp, Ls, dLs, z)
+        np.testing.assert_allclose(f, fo, rtol=1e-13, atol=1e-14)
+        assert np.max(np.abs(g - go)) <= 1e-12 * np.max(np.abs(go)), l
+        assert np.array_equal(f, ctx.approx_Lz(l, z))        # the value is the value-only call's, bit for bit
+    l = lp[6] + 0.4 * (lp[7] - lp[6]); h = 1e-6
+    _, g = ctx.approx_Lz_grad(l, z)
+    fd = (ctx.approx_Lz(l + h, z) - ctx.approx_Lz(l - h, z)) / (2 * h)
+    assert np.max(np.abs(g - fd)) <= 1e-8 * np.max(np.abs(g))
+    # host mirror
+    from gp_amd.covariance import approx_Lz_grad
+    f2, g2 = approx_Lz_grad(l, lp, Ls, dLs, z, ctx=ctx)
+    assert np.array_equal(g2, g)
+    ctx.interp_free()
+
+
+def test_approx_Lz_grad_many_chunks(ctx, orc):
+    rng = np.random.default_rng(11)
+    n = 1111
+    lp = np.array([1.0, 2.0, 2.5])
+    Ls = [np.tril(rng.standard_normal((n, n))) for _ in lp]
+    dLs = [np.tril(rng.standard_normal((n, n))) for _ in lp]
+    ctx.interp_load(lp, Ls, dLs)
+    z = rng.standard_normal(n)
+    for l in (1.3, 2.2):
+        f, g = ctx.approx_Lz_grad(l, z)
+        fo, go = orc.approx_Lz_grad(l, lp, Ls, dLs, z)
+        scale = np.abs(np.stack(Ls + dLs)).sum(axis=2).max()
+        assert np.max(np.abs(f - fo)) <= 1e-12 * scale and np.max(np.abs(g - go)) <= 1e-11 * scale
+        assert np.array_equal(g, ctx.approx_Lz_grad(l, z)[1])  # fixed summation order
+    ctx.interp_free()
+
+
+def test_table_built_on_lanes_equals_single_factorisations(ctx, orc):
+    """gpmi_interp_build factors the P entries concurrently on the grid lanes (entry p on lane p mod 4):
+    every entry must equal a stand-alone gpmi_rbf_cov_chol of the same length-scale bit for bit, at a
+    size with several panels, for P not a multiple of the lane count, and with lanes = 1."""
+    n = 700
+    x = 1.2 * np.arange(n) + 0.2 * np.sin(np.arange(n))
+    lp = np.linspace(0.7, 1.0, 7)
+    singles = [ctx.rbf_cov_chol(x, l) for l in lp]
+    for lanes in (0, 1, 3):
+        ctx.set_option("grid_lanes", lanes)
+        try:
+            ctx.interp_build(x, lp)
+        finally:
+            ctx.set_option("grid_lanes", 0)
+        for p, l in enumerate(lp):
+            assert np.array_equal(ctx.approx_L(l), singles[p][0]), (lanes, p)   # t = 0 or 1: the knot itself
+        z = np.sin(np.arange(n) * 0.1)
+        _, g = ctx.approx_Lz_grad(lp[2] + 1e-13, z)   # just right of knot 2: dv/dl = dLdl[2]
+        np.testing.assert_allclose(g, singles[2][1] @ z, rtol=0, atol=1e-8 * np.max(np.abs(g)))
+    ctx.interp_free()
+    # a failed factorisation (NaN input: no positive pivot) is reported through the lanes as well
+    import gp_amd
+    xb = np.arange(40.0); xb[7] = np.nan
+    with pytest.raises(gp_amd.NotPositiveDefinite):
+        ctx.interp_build(xb, [0.5, 0.8, 0.9])
+    ctx.interp_free()

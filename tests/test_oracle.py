@@ -1,5 +1,7 @@
 """CPU: pin the oracle (oracle/gp_oracle.c) against the golden fixtures and independent
 implementations before anything trusts it."""
+import math
+
 import numpy as np
 import pytest
 import scipy.linalg as sla
@@ -227,3 +229,50 @@ def test_seq_sampler_chain_equals_joint(orc):
     c = orc.create_p_dotXnS([X[:, 0]], mn, Kn, 1.3, 0.8, compat_sd=True)
     r = c([3.1], 0.3)
     assert r["dot_xs"] == r["mu"] + r["sigma"] * 0.3
+
+
+def test_oracle_vs_reference_ch2_cells(orc, golden):
+    """tests/golden/ch2.json: outputs of the reference's own ch2.py GP cells (its makeK at N = 1000,
+    numpy.linalg.solve posterior).  makeK is eta2 exp(-(x1-x2)^2 / l2): alpha^2 = eta2, rho^2 = l2 / 2."""
+    for cell in golden["ch2"]["cells"]:
+        N = cell["N"]; alpha = math.sqrt(cell["eta2"]); rho = math.sqrt(cell["l2"] / 2.0)
+        xs = np.linspace(0.0, 1.0, N); xd = np.array(cell["xd"]); f = np.array(cell["f"])
+        ri = np.array(cell["rows"]); ci = np.array(cell["cols"])
+        tol = 64 * np.finfo(float).eps * cell["eta2"]   # (x1-x2)^2 / l2 up to 20: a few ulp of the argument
+        Kss = orc.QQ(xs, xs, alpha, rho)
+        assert np.max(np.abs(Kss[np.ix_(ri, ci)] - np.array(cell["Kss_sample"]))) <= tol
+        Ksd = orc.QQ(xs, xd, alpha, rho)
+        assert np.max(np.abs(Ksd[ri, :] - np.array(cell["Ksd"]))) <= tol
+        Kdd = orc.QQ(xd, xd, alpha, rho)
+        assert np.max(np.abs(Kdd + cell["sigma2"] * np.eye(xd.size) - np.array(cell["Kdd"]))) <= tol
+        mn, Kn = orc.gp_condition(Kdd, Ksd, Kss, f, cell["sigma2"], 0.0)
+        m_ref = np.array(cell["m"])
+        assert np.max(np.abs(mn - m_ref)) <= 1e-11 * np.max(np.abs(m_ref))
+        assert np.max(np.abs(Kn[np.ix_(ri, ci)] - np.array(cell["Kt_sample"]))) <= 1e-11 * cell["eta2"]
+        assert np.max(np.abs(np.diag(Kn) - np.array(cell["Kt_diag"]))) <= 1e-11 * cell["eta2"]
+        # the same numbers through the D-dimensional builder (QQard) and the Stan-style one
+        assert np.max(np.abs(orc.QQard(xs[ri].reshape(-1, 1), xs[ci].reshape(-1, 1), alpha, [rho])
+                             - np.array(cell["Kss_sample"]))) <= tol
+
+
+def test_approx_Lz_grad_is_the_derivative_of_approx_Lz(orc):
+    """models/cubic_interpolated_gp.hpp:6-32,62-72: the `var` overload gives output i the partial
+    (dvdl z)(i) with respect to l.  No reference output exists (Stan is absent): the restated dvdl is
+    pinned by central differences of the (already pinned) value orc_approx_Lz inside one interval, by the
+    Hermite end conditions dv/dl = dLdl at the knots, and by the value being unchanged."""
+    x = np.linspace(0, 10, 30)
+    from scipy.stats import gamma
+    lp = np.linspace(gamma.ppf(0.05, 4.0, scale=0.25), gamma.ppf(0.95, 4.0, scale=0.25), 10)   # test_interpolate.R:9
+    Ls, dLs = zip(*[orc.rbf_cov_chol(x, l) for l in lp])
+    z = np.cos(0.7 * np.arange(30.0))
+    for l in (0.5 * (lp[0] + lp[1]), lp[3] + 0.3 * (lp[4] - lp[3]), lp[8] + 0.9 * (lp[9] - lp[8])):
+        f, g = orc.approx_Lz_grad(l, lp, Ls, dLs, z)
+        np.testing.assert_allclose(f, orc.approx_Lz(l, lp, Ls, dLs, z), rtol=1e-15, atol=1e-16)
+        h = 1e-6
+        fd = (orc.approx_Lz(l + h, lp, Ls, dLs, z) - orc.approx_Lz(l - h, lp, Ls, dLs, z)) / (2 * h)
+        np.testing.assert_allclose(g, fd, rtol=0, atol=1e-8 * np.max(np.abs(g)))
+    for k in (0, 4, 8):   # just right of a knot: dv/dl -> dLdl[k]
+        _, g = orc.approx_Lz_grad(lp[k] + 1e-13, lp, Ls, dLs, z)
+        np.testing.assert_allclose(g, dLs[k] @ z, rtol=0, atol=1e-9 * np.max(np.abs(g)))
+    _, g = orc.approx_Lz_grad(lp[5] - 1e-13, lp, Ls, dLs, z)   # ... and just left of one
+    np.testing.assert_allclose(g, dLs[5] @ z, rtol=0, atol=1e-9 * np.max(np.abs(g)))
