@@ -443,10 +443,19 @@ constexpr int GT = 128, GK = 16, GP = 144;
 // through that XCD's L2 (16 blocks per 64 tiles instead of ~65 in row-major order), which
 // takes the operand stream off HBM / Infinity Cache.  Tiles of a super-tile that fall outside
 // the triangle exit at once.
+// TN < T: the lower TRAPEZOID of a T x TN tile grid (a block column of the trailing matrix, the
+// first part of a look-ahead update): the TN x TN triangle first, then the rows below it.
 constexpr int ST = 8;
-__device__ __forceinline__ bool syrk_tile(int b, int T, int order, int &ti, int &tj)
+__device__ __forceinline__ bool syrk_tile(int b, int T, int TN, int order, int &ti, int &tj)
 {
-    if (order == 0) {  // plain row-major walk of the lower triangle
+    if (order == 0) {  // plain row-major walk of the lower triangle / trapezoid
+        const int tri = TN * (TN + 1) / 2;
+        if (b >= tri) {
+            const int q = b - tri;
+            ti = TN + q / TN;
+            tj = q % TN;
+            return ti < T;
+        }
         int i = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
         while ((i + 1) * (i + 2) / 2 <= b) ++i;
         while (i * (i + 1) / 2 > b) --i;
@@ -467,9 +476,9 @@ __device__ __forceinline__ bool syrk_tile(int b, int T, int order, int &ti, int 
     tj = J * ST + (local / ST);
     return ti < T && tj <= ti;
 }
-__host__ inline int syrk_grid(int T, int order)
+__host__ inline int syrk_grid(int T, int TN, int order)
 {
-    if (order == 0) return T * (T + 1) / 2;
+    if (order == 0) return TN * (TN + 1) / 2 + (T - TN) * TN;
     const int nst = (T + ST - 1) / ST;
     const int ns = nst * (nst + 1) / 2;
     return ((ns + 7) / 8) * 8 * ST * ST;
@@ -924,9 +933,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     int ti, tj;
     if (MODE == 1) {
         int b = blockIdx.x;
+        const int T = (M + GT - 1) / GT;
+        const int TN = (N + GT - 1) / GT < T ? (N + GT - 1) / GT : T;
         if (ks.S > 1 && b >= ks.bfull) {
             const int q = b - ks.bfull;
-            if (!syrk_tile(ks.bfull + (q >> 2), (M + GT - 1) / GT, order & 0xff, ti, tj)) return;
+            if (!syrk_tile(ks.bfull + (q >> 2), T, TN, order & 0xff, ti, tj)) return;
             const int qm = q & 1, qn = (q >> 1) & 1;
             if (ti == tj && qn > qm) return;  // strictly upper quadrant of a diagonal tile
             const int m0 = ti * GT + qm * 64, n0 = tj * GT + qn * 64;
@@ -935,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
                         N - n0, (int)threadIdx.x);
             return;
         }
-        if (!syrk_tile(b, (M + GT - 1) / GT, order & 0xff, ti, tj)) return;
+        if (!syrk_tile(b, T, TN, order & 0xff, ti, tj)) return;
         // order bit 8: the panel is UPPER TRIANGULAR (P[i][k] = 0 for k < i, e.g. L^-T): the
         // products of tile (ti, tj), tj <= ti, start at column ti * 128 -- a third of the work of
         // the full update; row-major tile order runs the long tiles first
@@ -1047,7 +1058,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_persist(const double *__restric
             __syncthreads();
             if (b >= ntiles) break;
             int ti, tj;
-            if (!syrk_tile(b, T, order, ti, tj)) continue;
+            if (!syrk_tile(b, T, T, order, ti, tj)) continue;
             // opaque copy of the thread index: keeps the lane-derived addresses of one tile from being
             // hoisted out of the loop, where they would sit on top of the 250-register tile body
             int tid = (int)threadIdx.x;
@@ -1085,7 +1096,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const double *__restrict__ A, 
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
     int ti, tj;
     if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, (M + GT - 1) / GT, order, ti, tj)) return;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1259,7 +1270,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm9(const double *__restrict__ A, 
     __shared__ __attribute__((aligned(16))) double smem[3][2][GK][GP];
     int ti, tj;
     if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, order, ti, tj)) return;
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, (M + GT - 1) / GT, order, ti, tj)) return;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1649,14 +1660,16 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
 {
     if (tri && M > 0 && N > 0 && K > 0) {  // upper-triangular panel: plain kernel, row-major tiles, zero K-range skipped
         const int T = (M + GT - 1) / GT;
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(syrk_grid(T, 0)), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, 0x100, 0,
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(syrk_grid(T, T, 0)), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, 0x100, 0,
                            FuseDiag{}, KSplit{});
         return false;
     }
     if (M <= 0 || N <= 0 || K <= 0) return false;
     const int T = (M + GT - 1) / GT;
-    const int syrk_order = c->tune.syrk_order;
-    const int ntiles = syrk_grid(T, syrk_order);
+    // N < M: lower trapezoid (block column of a look-ahead update), row-major order only
+    const int TNf = (N + GT - 1) / GT, TN = TNf < T ? TNf : T;
+    const int syrk_order = TN < T ? 0 : c->tune.syrk_order;
+    const int ntiles = syrk_grid(T, TN, syrk_order);
     const int stg = ntiles >= 1024 ? c->tune.stagger : 0;  // only when every CU holds two workgroups for many rounds
 #ifdef GPMI_PROBES
     if (c->tune.gemm_variant == 2) {
@@ -1695,7 +1708,7 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
         // per tile (2.4 % of all tiles at N = 16384); as quadrants only the MFMA tiles that hold
         // valid rows are multiplied (1/8 of the work).
         const int vlast = M - (T - 1) * GT;
-        if (T > 1 && vlast <= 64 && ntiles - T < first) first = ntiles - T;
+        if (T > 1 && vlast <= 64 && ntiles - TN < first) first = ntiles - TN;  // the last tile row has TN tiles
         if (first < ntiles) {
             ks = KSplit{first, 4};
             grid = first + 4 * (ntiles - first);
@@ -1820,7 +1833,14 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     // number of epilogues once the trailing matrix is large; 256 keeps the panel phase short.
     auto nbo_for = [](int cols) { return cols >= 12288 ? 1024 : (cols >= 6144 ? 512 : 256); };
     const int NBO = c->nb_outer > 0 ? c->nb_outer : nbo_for(nfac);
-    const bool la = c->lookahead > 0 && c->pstream && nfac > NBO && NBO / GPMI_NB <= GPMI_FPACK_SLOTS;
+    // look-ahead needs at least three outer blocks to pay, a second stream, and the block's packed
+    // factors in the ring (or all kept)
+    bool la = c->lookahead > 0 && nfac >= 3 * NBO && (Fpack_all || NBO / GPMI_NB <= GPMI_FPACK_SLOTS);
+    if (la) {
+        int rc = gpmi_lookahead_streams(c);
+        if (rc) return rc;
+        la = c->nq >= 2 || c->pstream;
+    }
     if (!la) {
         hipStream_t s = c->stream;
         // auto width follows the columns still to factor (tune.nb_adapt): the last blocks of a large
@@ -1849,55 +1869,82 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(ke - ko), s);
         }
     } else {
-        // One-block look-ahead (opt-in).  The panel phase is split by rows:
-        //   Diag(s) : the NBO x NBO diagonal block -- 8 x (potrf_diag, narrow solve, narrow update),
-        //             a pure latency chain of few-workgroup kernels          -> priority stream
-        //   Rows(s) : the panel solve for the rows below it -- wide kernels   -> bulk stream
-        // and the trailing update with block s into
-        //   U1a(s)  : the next diagonal block (all Diag(s+1) needs)           -> bulk stream
-        //   U1b(s), U2(s) : the rest                                          -> bulk stream
-        // Diag(s+1) runs on a few CUs while U1b(s) and U2(s) fill the chip.  The bulk stream may
-        // be CU-masked (cu_reserve): potrf_diag needs a whole CU's LDS and would otherwise wait
-        // for one to drain by chance while SYRK workgroups refill every slot that frees up.
-        const bool masked = c->cu_reserve > 0 && c->mstream;
-        hipStream_t sb = masked ? c->mstream : c->stream, sc = c->pstream;
-        hipEventRecord(c->evM, c->stream);
-        if (masked) hipStreamWaitEvent(sb, c->evM, 0);
-        hipStreamWaitEvent(sc, c->evM, 0);
+        // Look-ahead over outer blocks on TWO streams.  With U(j) the trailing update by block j,
+        // split by columns into U1(j) (block column j + 1, all rows below) and U2(j) (the rest):
+        //   sB (panel stream): P(0) | U1(0) P(1) | U1(1) P(2) | ...   U1(j) waits for U2(j - 1)
+        //   sA (bulk stream):        | U2(0)      | U2(1)      | ...   U2(j) waits for P(j)
+        // The latency-bound panel phase P(j + 1) -- 8 x (diagonal block, panel solve, in-block
+        // product) per 1024 columns, a chain of small kernels -- and the thin U1(j) run while U2(j)
+        // fills the chip from the other stream: sA goes from one bulk update straight into the next
+        // as long as U1(j) + P(j + 1) take less time than U2(j).  The two streams are the context's
+        // calibrated dispatch streams (hardware queues on different command-processor pipes: kernels
+        // of queues that share a pipe are time-sliced instead of overlapped).
+        hipStream_t const caller = c->stream;
+        hipStream_t sA = caller, sB = c->pstream;
+        if (c->nq >= 2) {
+            sA = c->qstream[0];
+            sB = c->qstream[1];
+        }
+        hipEventRecord(c->evM, caller);
+        if (sA != caller) hipStreamWaitEvent(sA, c->evM, 0);
+        hipStreamWaitEvent(sB, c->evM, 0);
         {
             const int ke0 = NBO < nfac ? NBO : nfac;
-            panel_rows(c, W, ld, d_info, Fpack_all, 0, ke0, NBO, 0, ke0, true, sc);
-            hipEventRecord(c->evP, sc);
+            kt_begin(c, 2, sB);
+            panel_rows(c, W, ld, d_info, Fpack_all, 0, ke0, NBO, 0, M, true, sB);
+            const double w = (double)ke0, m = (double)M;
+            kt_end(c, 2, w * w * (m - w) + w * w * w / 3.0, sB);
+            hipEventRecord(c->evP, sB);
         }
+        bool u2_pending = false;
         for (int ko = 0; ko < nfac; ko += NBO) {
             const int ke = (ko + NBO < nfac) ? ko + NBO : nfac;
             const int K = ke - ko;
-            hipStreamWaitEvent(sb, c->evP, 0);  // Diag(s) done
-            if (ke < M) panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, NBO, ke, M, false, sb);
-            if (ke >= M || ke >= ncol) continue;
-            if (ke < nfac) {
-                const int ke2 = (ke + NBO < nfac) ? ke + NBO : nfac;
-                launch_syrk_lower(c, sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
-                                  ke2 - ke, ke2 - ke, K, c->d_ctr, c->ncu);
-                hipEventRecord(c->evU, sb);
-                hipStreamWaitEvent(sc, c->evU, 0);
-                panel_rows(c, W, ld, d_info, Fpack_all, ke, ke2, NBO, 0, ke2, true, sc);
-                hipEventRecord(c->evP, sc);
-                if (ke2 < M)
-                    launch_gemm_nt(c, sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ko * ld, ld,
-                                   W + (size_t)ke2 + (size_t)ke * ld, ld, M - ke2, ke2 - ke, K, 1);
-                if (ke2 < M && ke2 < ncol)
-                    launch_syrk_lower(c, sb, W + (size_t)ke2 + (size_t)ko * ld, ld, W + (size_t)ke2 + (size_t)ke2 * ld,
-                                      ld, M - ke2, ncol - ke2, K, c->d_ctr, c->ncu);
-            } else {  // last factored block: Schur complement / augmented rows
-                launch_syrk_lower(c, sb, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
-                                  M - ke, ncol - ke, K, c->d_ctr, c->ncu);
+            if (ke >= M || ke >= ncol) break;
+            const double *Pj = W + (size_t)ko * ld;   // panel j: rows [ke, M) of columns [ko, ke)
+            if (ke >= nfac) {  // last factored block: Schur complement / augmented rows, nothing follows
+                hipStreamWaitEvent(sA, c->evP, 0);
+                const double mt = (double)(ncol - ke), extra = (double)(M - ncol);
+                kt_begin(c, 1, sA);
+                launch_syrk_lower(c, sA, Pj + ke, ld, W + (size_t)ke + (size_t)ke * ld, ld, M - ke, ncol - ke, K, c->d_ctr, c->ncu);
+                kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)K, sA);
+                break;
             }
+            const int ke2 = (ke + NBO < nfac) ? ke + NBO : nfac;
+            const int w1 = ke2 - ke;
+            // U1(j) on sB: rows [ke, M) x columns [ke, ke2); its tile (0, 0) is the next diagonal block
+            if (u2_pending) hipStreamWaitEvent(sB, c->evU, 0);
+            FuseDiag fd{fpack_slot(c, Fpack_all, ke, ke), d_info, ke, (nfac - ke < GPMI_NB) ? nfac - ke : GPMI_NB, nullptr};
+            kt_begin(c, 1, sB);
+            const bool fused = launch_syrk_lower(c, sB, Pj + ke, ld, W + (size_t)ke + (size_t)ke * ld, ld, M - ke, w1, K, c->d_ctr,
+                                                 c->ncu, 0, &fd);
+            kt_end(c, 1, ((double)w1 * ((double)w1 + 1.0) + 2.0 * (double)(M - ke2) * (double)w1) * (double)K, sB);
+            // U2(j) on sA: rows [ke2, M) x columns [ke2, ncol)
+            u2_pending = false;
+            if (ke2 < M && ke2 < ncol) {
+                hipStreamWaitEvent(sA, c->evP, 0);
+                const double mt = (double)(ncol - ke2), extra = (double)(M - ncol);
+                kt_begin(c, 1, sA);
+                launch_syrk_lower(c, sA, Pj + ke2, ld, W + (size_t)ke2 + (size_t)ke2 * ld, ld, M - ke2, ncol - ke2, K, c->d_ctr, c->ncu);
+                kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)K, sA);
+                hipEventRecord(c->evU, sA);
+                u2_pending = true;
+            }
+            // P(j + 1) on sB
+            kt_begin(c, 2, sB);
+            panel_rows(c, W, ld, d_info, Fpack_all, ke, ke2, NBO, 0, M, true, sB, fused);
+            {
+                const double w = (double)w1, m = (double)(M - ke);
+                kt_end(c, 2, w * w * (m - w) + w * w * w / 3.0, sB);
+            }
+            hipEventRecord(c->evP, sB);
         }
-        hipEventRecord(c->evM, sb);
-        if (masked) hipStreamWaitEvent(c->stream, c->evM, 0);
-        hipEventRecord(c->evU, sc);
-        hipStreamWaitEvent(c->stream, c->evU, 0);
+        if (sA != caller) {
+            hipEventRecord(c->evM, sA);
+            hipStreamWaitEvent(caller, c->evM, 0);
+        }
+        hipEventRecord(c->evU, sB);
+        hipStreamWaitEvent(caller, c->evU, 0);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "potrf launch failed: %s", hipGetErrorString(e));

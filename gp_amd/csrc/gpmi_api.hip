@@ -184,36 +184,15 @@ static int calibrate_streams(gpmi_ctx *c)
     return 0;
 }
 
-// (re)create the CU-masked trailing-update stream for the current cu_reserve / mode
-int ensure_mstream(gpmi_ctx *c)
+int gpmi_lookahead_streams(gpmi_ctx *c)
 {
-    static_assert(sizeof(uint32_t) == 4, "");
-    if (c->cu_reserve <= 0) return 0;
-    if (c->mstream) return 0;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, c->device));
-    const int ncu = prop.multiProcessorCount;
-    const int words = (ncu + 31) / 32;
-    std::vector<uint32_t> mask(words, 0xFFFFFFFFu);
-    if (ncu % 32) mask[words - 1] = (1u << (ncu % 32)) - 1u;
-    const int nres = c->cu_reserve < ncu / 2 ? c->cu_reserve : ncu / 2;
-    for (int r = 0; r < nres; ++r) {
-        const int bit = c->cu_mask_mode == 1 ? r : (int)(((long long)r * ncu) / nres);
-        mask[bit / 32] &= ~(1u << (bit % 32));
+    if (c->calibrate && c->nq == 0) {
+        int rc = calibrate_streams(c);
+        if (rc) return rc;
     }
-    HIPCHK(hipExtStreamCreateWithCUMask(&c->mstream, (uint32_t)words, mask.data()));
+    if (c->nq >= 2) return 0;
+    if (!c->pstream) HIPCHK(hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
     return 0;
-}
-
-// streams of the look-ahead: priority stream for the diagonal-block chain (+ masked bulk stream)
-static int ensure_aux_streams(gpmi_ctx *c)
-{
-    if (!c->pstream) {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, greatest));
-    }
-    return ensure_mstream(c);
 }
 
 // ---- context ---------------------------------------------------------------
@@ -261,12 +240,7 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
         HIPCHK(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
-        c->lookahead = -1;  // -1 / 0: off (default), 1: on (see launch_potrf_partial)
-        // Auxiliary streams (priority panel stream, optional CU-masked bulk stream) exist only while
-        // look-ahead is switched on: every extra hardware queue shifts the queue -> pipe layout
-        // the grid lanes depend on, and CU-masked queues dispatch markedly slower than plain ones.
-        c->cu_reserve = 0;
-        c->cu_mask_mode = 1;
+        c->lookahead = -1;  // -1: auto (see launch_potrf_partial), 0: off, 1: on
         c->calibrate = 1;
     }
     HIPCHK(hipMalloc((void **)&c->Fpack, (size_t)GPMI_FPACK_SLOTS * GPMI_FPACK * sizeof(double)));
@@ -304,10 +278,6 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         if (c->pstream) {
             hipStreamSynchronize(c->pstream);
             hipStreamDestroy(c->pstream);
-        }
-        if (c->mstream) {
-            hipStreamSynchronize(c->mstream);
-            hipStreamDestroy(c->mstream);
         }
         hipEventDestroy(c->evM);
         hipEventDestroy(c->evFork);
@@ -355,17 +325,6 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
             return gpmi_fail(GPMI_EARG, "nb_outer must be 0 (auto) or a multiple of %d", GPMI_NB);
         c->nb_outer = value;
         return 0;
-    }
-    if (!strcmp(name, "cu_reserve") || !strcmp(name, "cu_mask_mode")) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->mstream) {
-            HIPCHK(hipStreamSynchronize(c->mstream));
-            HIPCHK(hipStreamDestroy(c->mstream));
-            c->mstream = nullptr;
-        }
-        if (!strcmp(name, "cu_reserve")) c->cu_reserve = value;
-        else c->cu_mask_mode = value;
-        return c->lookahead > 0 ? ensure_mstream(c) : 0;
     }
     if (!strcmp(name, "stagger")) {
         c->tune.stagger = value;
@@ -415,8 +374,8 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         return 0;
     }
     if (!strcmp(name, "debug_topology")) {  // prints which of the context's streams dispatch concurrently
-        hipStream_t st[4] = {c->stream, c->own_stream, c->pstream, c->mstream};
-        const char *nm[4] = {"stream", "own", "panel", "masked"};
+        hipStream_t st[4] = {c->stream, c->own_stream, c->pstream, c->nq > 1 ? c->qstream[1] : nullptr};
+        const char *nm[4] = {"stream", "own", "panel", "q1"};
         for (int a = 0; a < 4; ++a) {
             fprintf(stderr, "%8s:", nm[a]);
             for (int b = 0; b < 4; ++b) {
@@ -445,9 +404,9 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->grid_lanes = value;
         return 0;
     }
-    if (!strcmp(name, "lookahead")) {  // 1 on; 0 / -1 off (default)
+    if (!strcmp(name, "lookahead")) {  // panel look-ahead on two streams: 1 on, 0 off, -1 auto (default)
         c->lookahead = value;
-        return value > 0 ? ensure_aux_streams(c) : 0;
+        return 0;
     }
     if (!strcmp(name, "timing")) {
         c->timing = value != 0;
@@ -787,14 +746,7 @@ static int lanes_prepare(gpmi_ctx *c, int lanes)
         lc->tune = c->tune;
         lc->nb_outer = c->nb_outer;
         lc->lookahead = c->lane_lookahead;  // default 0: concurrent lanes already fill the panel phases
-        if (c->lane_lookahead) {
-            int rc = ensure_aux_streams(lc);
-            if (rc) return rc;
-        }
-    }
-    if (lanes > 1 && c->lane_lookahead) {
-        int rc = ensure_aux_streams(c);
-        if (rc) return rc;
+        lc->calibrate = 0;                  // a lane never probes for streams of its own
     }
     if (lanes > 1 && c->calibrate) {
         int rc = calibrate_streams(c);

@@ -55,11 +55,8 @@ struct gpmi_ctx {
     double *stage[4];
     size_t stage_bytes[4];
     int nb_outer;            // outer panel width (multiple of GPMI_NB)
-    int lookahead;           // factor the next panel on pstream while the trailing update runs
-    hipStream_t pstream;     // high-priority panel stream
-    hipStream_t mstream;     // CU-masked stream for the trailing updates (leaves cu_reserve CUs free)
-    int cu_reserve;          // CUs kept out of the trailing-update stream's mask (0 = no masking)
-    int cu_mask_mode;        // 0: reserve CU bits strided over the mask, 1: the lowest bits
+    int lookahead;           // two-stream look-ahead over outer blocks: -1 auto, 0 off, 1 on
+    hipStream_t pstream;     // panel stream of the look-ahead when no calibrated pair exists
     hipEvent_t evM;
     hipEvent_t evP, evU;     // panel done / next-panel columns updated
     int timing;
@@ -91,7 +88,7 @@ struct gpmi_ctx {
 // event-pair recorder; begin/end bracket one launch on the context's stream
 void kt_begin(gpmi_ctx *c, int cat, hipStream_t s = nullptr);
 void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t s = nullptr);
-int ensure_mstream(gpmi_ctx *c);
+int gpmi_lookahead_streams(gpmi_ctx *c);  // two concurrently dispatching streams for the look-ahead (calibrated, or a panel stream)
 
 // ---- error plumbing -------------------------------------------------------
 int gpmi_fail(int code, const char *fmt, ...);

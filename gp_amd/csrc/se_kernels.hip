@@ -55,16 +55,19 @@ static const ExpC h_exp = {{
     1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
     1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0,
     -800.0}};
-__device__ __forceinline__ double exp_nonpos(double x, const ExpC &e)
+__device__ __forceinline__ double exp_nonpos(double xin, const ExpC &e)
 {
-    x = fmax(x, e.c[17]);
+    double x = fmax(xin, e.c[17]);  // (v_max_f64 drops a NaN operand: put back by the last fma)
     const double n = rint(x * e.c[0]);
     double r = fma(n, e.c[1], x);
     r = fma(n, e.c[2], r);
     double p = e.c[3];
 #pragma unroll
     for (int k = 4; k <= 16; ++k) p = fma(p, r, e.c[k]);
-    return ldexp(p, (int)n);
+    // + 0 * xin: a NaN coordinate gives a NaN covariance, like exp(NaN) in R and the not_nan check of
+    // Stan's cov_exp_quad -- the factorisation then reports "not positive definite" instead of
+    // silently treating the point as infinitely far away
+    return fma(xin, 0.0, ldexp(p, (int)n));
 }
 
 // K[i,j] = a2 * exp(-1/2 sum_d ((X[i,d]-Y[j,d]) * inv_ell[d])^2), diag_add on i == j if same.

@@ -81,6 +81,22 @@ def test_nan_input_is_flagged_not_crashed(ctx):
     assert math.isnan(r[0]) or math.isnan(r[2])
 
 
+def test_nan_coordinate_gives_nan_covariance_and_not_pd(ctx):
+    # exp(NaN) is NaN in R (R/kernels.R:14) and Stan's cov_exp_quad rejects NaN inputs: a NaN point must not
+    # silently become "infinitely far away" (covariance 0) through the clamped exp of the build kernel
+    import gp_amd
+    X = np.linspace(0, 1, 40).reshape(-1, 1).copy(); X[7, 0] = np.nan
+    K = ctx.se_cov(X, None, 1.0, [0.3])
+    off = ~np.eye(40, dtype=bool)
+    assert np.all(np.isnan(K[7, off[7]])) and np.all(np.isnan(K[off[:, 7], 7]))
+    assert np.all(np.isfinite(np.delete(np.delete(K, 7, 0), 7, 1)))
+    with pytest.raises(gp_amd.NotPositiveDefinite):
+        ctx.logml(X, np.ones(40), 1.0, [0.3], 0.1)
+    Xb = np.random.default_rng(1).random((30, 12)); Xb[3, 11] = np.nan    # the D > 8 builder
+    Kb = ctx.se_cov(Xb, None, 1.0, [0.5])
+    assert np.isnan(Kb[3, 5]) and np.isnan(Kb[5, 3]) and np.isfinite(Kb[4, 5])
+
+
 def test_context_is_rejected_in_forked_child(ctx):
     # HIP state does not survive fork(): the parent's context must answer GPMI_EFORK (-5) in a
     # child (the reference drivers fork with parallel::mclapply, pendulum_fit.R:268)
