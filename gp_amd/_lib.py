@@ -29,7 +29,7 @@ SYMBOLS = (
     "gpmi_last_timing", "gpmi_kernel_timing",
 )
 # additionally exported by the probe build (libgpmi_probes.so, -DGPMI_PROBES; tools/ only)
-PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak")
+PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock")
 
 
 class GpmiError(RuntimeError):
@@ -405,6 +405,14 @@ class Context:
         ms = C.c_double(0.0)
         _chk(self._probe("gpmi_probe_syrk")(self._h, int(m), int(k), int(reps), C.byref(ms)))
         return ms.value, m * (m + 1.0) * k / (ms.value * 1e-3) / 1e12
+
+    def probe_clock(self, reset=True):
+        """(avg shader clock MHz, avg cycles per SYRK workgroup, workgroups) since the last reset."""
+        out = np.zeros(3)
+        _chk(self._probe("gpmi_probe_clock")(self._h, int(bool(reset)), _p(out)))
+        if out[2] == 0:
+            return 0.0, 0.0, 0
+        return out[0] / max(out[1], 1.0) * 100.0, out[0] / out[2], int(out[2])
 
     def probe_mfma_peak(self, iters=20000):
         t = C.c_double(0.0); mhz = C.c_double(0.0)

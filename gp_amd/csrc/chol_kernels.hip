@@ -913,6 +913,12 @@ struct KSplit {
     int S;       // 4: quadrants; <= 1: no split
 };
 
+#ifdef GPMI_PROBES
+// shader-clock probe: per workgroup of the SYRK kernel, elapsed shader cycles (s_memtime) and elapsed
+// 100 MHz reference ticks (s_memrealtime), summed over the launch -> average clock and cycles per tile
+__device__ unsigned long long g_clk[4];
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
                                                  const double *__restrict__ B, size_t ldb,
@@ -926,6 +932,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     // in DESIGN.md.  They exist in the probe build only; here they fold to nothing.
 #ifdef GPMI_PROBES
     const int dbg = stagger >> 24;
+    struct ClkProbe {
+        unsigned long long t0, r0;
+        __device__ ClkProbe() : t0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()) {}
+        __device__ ~ClkProbe()
+        {
+            if (MODE == 1 && threadIdx.x == 0) {
+                atomicAdd(&g_clk[0], __builtin_amdgcn_s_memtime() - t0);
+                atomicAdd(&g_clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+                atomicAdd(&g_clk[2], 1ull);
+            }
+        }
+    } clk_probe;
 #else
     constexpr int dbg = 0;
 #endif
@@ -2045,6 +2063,19 @@ void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const 
 }
 
 #ifdef GPMI_PROBES
+int probe_clock_read(hipStream_t s, int reset, unsigned long long *out3)
+{
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), sizeof h) != hipSuccess) return 1;
+    for (int i = 0; i < 3; ++i) out3[i] = h[i];
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+
 void launch_probe_mfma(hipStream_t s, const double *A, const double *B, double *D)
 {
     hipLaunchKernelGGL(k_probe_mfma, dim3(1), 64, 0, s, A, B, D);

@@ -1885,6 +1885,18 @@ extern "C" int gpmi_probe_syrk(gpmi_ctx *c, int m, int k, int reps, double *ms)
     return 0;
 }
 
+int probe_clock_read(hipStream_t s, int reset, unsigned long long *out3);
+// out3: summed shader cycles, summed 100 MHz ticks, workgroups of all SYRK launches since the last reset
+extern "C" int gpmi_probe_clock(gpmi_ctx *c, int reset, double *out3)
+{
+    ENTER(c);
+    unsigned long long h[3];
+    if (probe_clock_read(c->stream, reset, h)) return gpmi_fail(GPMI_EHIP, "clock probe read failed");
+    if (out3)
+        for (int i = 0; i < 3; ++i) out3[i] = (double)h[i];
+    return 0;
+}
+
 extern "C" int gpmi_probe_mfma(gpmi_ctx *c, const double *A64, const double *B64, double *out256)
 {
     ENTER(c);

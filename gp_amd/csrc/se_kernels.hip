@@ -123,38 +123,78 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
     }
 }
 
-// Same for D > GPMI_MAXD (R's QQard takes any D): coordinates are re-read per element (L1/L2
-// resident), nothing is held in per-dimension registers.
+// Same for D > GPMI_MAXD (R's QQard takes any D): LDS-tiled pairwise distances.  The scaled
+// coordinates of the tile's 64 rows and 64 columns are staged in LDS in chunks of BIG_DC dimensions
+// (each (operand, dimension) row of 64 values is loaded and scaled by ONE wave: the dimension index
+// stays wave-uniform, so the inverse length-scales come out of the kernel arguments by scalar
+// loads); a thread keeps the 16 running sums of its 2 x 8 elements in registers and per dimension
+// reads its row pair (one 16-B LDS read) and 8 column values (two lanes groups per wave: broadcast
+// reads): 2 VALU instructions per element and dimension instead of the 3.5 + 1.5 cache loads of
+// re-reading the coordinates per element.  Compute-bound from D ~ 16 on (D = 64: 128 of ~170 VALU
+// instructions per element are the distance); measured rates in DESIGN.md section 5.
+constexpr int BIG_DC = 16;
 __global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X, int n, int ldx,
                                                     const double *__restrict__ Y, int m, int ldy,
                                                     SeParams p, double diag_add, int same, int lower,
                                                     double *__restrict__ K, size_t ldk, int vec, ExpC ec)
 {
+    static_assert(TILE == 64 && BIG_DC == 16, "staging index arithmetic below");
+    __shared__ __attribute__((aligned(16))) double sX[BIG_DC][TILE];
+    __shared__ __attribute__((aligned(16))) double sY[BIG_DC][TILE];
     const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
     if (lower && col0 > row0 + TILE - 1) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = row0 + 2 * tx;
     const bool ok0 = r < n, ok1 = r + 1 < n;
-    const int ra = ok0 ? r : 0, rb = ok1 ? r + 1 : 0;
+    // staging sources of this lane, clamped (rows / columns past the end are never stored)
+    const int xr = (row0 + lane < n) ? row0 + lane : n - 1;
+    const int yc = (col0 + lane < m) ? col0 + lane : m - 1;
+    double s0[8], s1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.0;
+    for (int d0 = 0; d0 < p.D; d0 += BIG_DC) {
+        const int dc = (p.D - d0 < BIG_DC) ? p.D - d0 : BIG_DC;
+        __syncthreads();  // the previous chunk has been consumed
+#pragma unroll
+        for (int k = 0; k < 2 * BIG_DC / 4; ++k) {
+            const int rowid = w + 4 * k;            // wave-uniform: operand = rowid >> 4, dimension = rowid & 15
+            const int dd = rowid & (BIG_DC - 1);
+            if (dd < dc) {
+                const double ie = p.inv_ell[d0 + dd];
+                if (rowid < BIG_DC) sX[dd][lane] = __dmul_rn(X[(size_t)xr + (size_t)(d0 + dd) * ldx], ie);
+                else sY[dd][lane] = __dmul_rn(Y[(size_t)yc + (size_t)(d0 + dd) * ldy], ie);
+            }
+        }
+        __syncthreads();
+        for (int dd = 0; dd < dc; ++dd) {
+            const double2 xv = *reinterpret_cast<const double2 *>(&sX[dd][2 * tx]);
+            const double2 *yp = reinterpret_cast<const double2 *>(&sY[dd][ty * 8]);
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const double2 yv = yp[q2];
+                const double a0 = __dsub_rn(xv.x, yv.x), a1 = __dsub_rn(xv.y, yv.x);
+                const double b0 = __dsub_rn(xv.x, yv.y), b1 = __dsub_rn(xv.y, yv.y);
+                s0[2 * q2] = fma(a0, a0, s0[2 * q2]);
+                s1[2 * q2] = fma(a1, a1, s1[2 * q2]);
+                s0[2 * q2 + 1] = fma(b0, b0, s0[2 * q2 + 1]);
+                s1[2 * q2 + 1] = fma(b1, b1, s1[2 * q2 + 1]);
+            }
+        }
+    }
+#pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = col0 + ty * 8 + q;
         if (c >= m) break;
-        double s0 = 0.0, s1 = 0.0;
-        for (int d = 0; d < p.D; ++d) {
-            const double ie = p.inv_ell[d];
-            const double yv = __dmul_rn(Y[(size_t)c + (size_t)d * ldy], ie);
-            const double d0 = __dsub_rn(__dmul_rn(X[(size_t)ra + (size_t)d * ldx], ie), yv);
-            const double d1 = __dsub_rn(__dmul_rn(X[(size_t)rb + (size_t)d * ldx], ie), yv);
-            s0 = fma(d0, d0, s0);
-            s1 = fma(d1, d1, s1);
-        }
-        double v0 = p.a2 * exp_nonpos(-0.5 * s0, ec), v1 = p.a2 * exp_nonpos(-0.5 * s1, ec);
+        double v0 = p.a2 * exp_nonpos(-0.5 * s0[q], ec), v1 = p.a2 * exp_nonpos(-0.5 * s1[q], ec);
         if (same) {
             if (r == c) v0 = p.a2 + diag_add;
             if (r + 1 == c) v1 = p.a2 + diag_add;
         }
         const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
-        store_pair(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
+        if (vec & 2) store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, true);
+        else store_pair<false>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
     }
 }
 
@@ -223,7 +263,7 @@ __global__ __launch_bounds__(256) void k_deriv_elem(int kind, const double *__re
 // (R/ode_gp_library.R:29-30): one exp per point pair feeds QQ, QR, RQ, RR.
 __global__ __launch_bounds__(256) void k_joint_cov(const double *__restrict__ t, int n, double a2,
                                                    double l2, double s2, double jitter, int compat,
-                                                   int lower, double *__restrict__ K, size_t ldk, int vec)
+                                                   int lower, double *__restrict__ K, size_t ldk, int vec, ExpC ec)
 {
     const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -238,7 +278,8 @@ __global__ __launch_bounds__(256) void k_joint_cov(const double *__restrict__ t,
         if (c >= n) break;
         const double yv = t[c];
         const double r0 = x0 - yv, r1 = x1 - yv;
-        const double e0 = exp(-(r0 * r0 / (2 * l2))), e1 = exp(-(r1 * r1 / (2 * l2)));
+        // same argument as derivative_kernels.R:39-41; the lean exp for x <= 0 (<= 1 ulp)
+        const double e0 = exp_nonpos(-(r0 * r0 / (2 * l2)), ec), e1 = exp_nonpos(-(r1 * r1 / (2 * l2)), ec);
         double qq0 = a2 * e0, qq1 = a2 * e1;
         const double qr0 = a2 * e0 * r0 * il2, qr1 = a2 * e1 * r1 * il2;
         double rr0 = a2 * e0 * il2 - a2rr * e0 * r0 * r0 * il2 * il2;
@@ -448,7 +489,7 @@ void launch_joint_cov(hipStream_t s, const double *dt, int n, double a2, double 
     if (n <= 0) return;
     dim3 grid((n + TILE - 1) / TILE, (n + TILE - 1) / TILE);
     hipLaunchKernelGGL(k_joint_cov, grid, 256, 0, s, dt, n, a2, l * l, s2, jitter, compat, lower, dK, ldk,
-                       (int)vec_ok(dK, ldk));
+                       (int)vec_ok(dK, ldk), h_exp);
 }
 
 void launch_set_row(hipStream_t s, double *W, size_t ld, int row, const double *src, int n, int ntotal)

@@ -270,6 +270,10 @@ GPMI_API int gpmi_kernel_timing(gpmi_ctx *ctx, int reset, double *out9);
  * P m x k: average ms per launch over `reps` back-to-back launches (HIP events). */
 GPMI_API int gpmi_probe_syrk(gpmi_ctx *ctx, int m, int k, int reps, double *ms);
 
+/* Shader-clock probe of the SYRK kernel: out3 = summed shader cycles, summed 100 MHz ticks and number of
+ * workgroups of every trailing-update launch since the last reset. */
+GPMI_API int gpmi_probe_clock(gpmi_ctx *ctx, int reset, double *out3);
+
 /* MFMA f64 fragment-layout probe: D = A(16x4) * B(4x16) on one wave with the
  * library's fragment conventions; out256 row-major D[i][j].  Host buffers. */
 GPMI_API int gpmi_probe_mfma(gpmi_ctx *ctx, const double *A64, const double *B64, double *out256);
