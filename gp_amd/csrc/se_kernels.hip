@@ -123,63 +123,72 @@ __global__ __launch_bounds__(256) void k_se_cov(const double *__restrict__ X, in
     }
 }
 
-// Same for D > GPMI_MAXD (R's QQard takes any D): LDS-tiled pairwise distances.  The scaled
-// coordinates of the tile's 64 rows and 64 columns are staged in LDS in chunks of BIG_DC dimensions
-// (each (operand, dimension) row of 64 values is loaded and scaled by ONE wave: the dimension index
-// stays wave-uniform, so the inverse length-scales come out of the kernel arguments by scalar
-// loads); a thread keeps the 16 running sums of its 2 x 8 elements in registers and per dimension
-// reads its row pair (one 16-B LDS read) and 8 column values (two lanes groups per wave: broadcast
-// reads): 2 VALU instructions per element and dimension instead of the 3.5 + 1.5 cache loads of
-// re-reading the coordinates per element.  Compute-bound from D ~ 16 on (D = 64: 128 of ~170 VALU
-// instructions per element are the distance); measured rates in DESIGN.md section 5.
-constexpr int BIG_DC = 16;
+// Any D (R's QQard takes any D, R/kernels.R:11-19; D = 1, 2, 3 have the register-resident kernel
+// above): LDS-tiled pairwise distances.  A workgroup owns 128 rows x 64 columns; the scaled
+// coordinates of those rows and columns are staged in LDS in chunks of BIG_DC dimensions (each
+// (operand, dimension) row of 64 values is loaded and scaled by ONE wave: the dimension index stays
+// wave-uniform, so the inverse length-scales come out of the kernel arguments by scalar loads).  A
+// thread keeps the 32 running sums of its 4 rows x 8 columns in registers (rows 2 tx, 2 tx + 1 and the
+// same pair 64 rows further down: every 16-B store instruction of a wave then covers 512 contiguous
+// bytes of a column; four consecutive rows per lane leave every 64-B segment half written and cost 2x)
+// and reads, per dimension,
+// its 4 row values (two 16-B LDS reads) and 8 column values (four 16-B broadcast reads): 2 VALU
+// instructions and 0.19 LDS reads per element and dimension -- with 2 x 8 elements per thread the
+// LDS pipe (5 reads per 16 elements) was the bound, not the VALU.  Compute-bound from D ~ 8 on
+// (D = 64: 128 of ~170 VALU instructions per element are the distance); measured rates in DESIGN.md
+// section 5.
+constexpr int BIG_DC = 16, BIG_TR = 128, BIG_TC = 64;
 __global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X, int n, int ldx,
                                                     const double *__restrict__ Y, int m, int ldy,
                                                     SeParams p, double diag_add, int same, int lower,
                                                     double *__restrict__ K, size_t ldk, int vec, ExpC ec)
 {
-    static_assert(TILE == 64 && BIG_DC == 16, "staging index arithmetic below");
-    __shared__ __attribute__((aligned(16))) double sX[BIG_DC][TILE];
-    __shared__ __attribute__((aligned(16))) double sY[BIG_DC][TILE];
-    const int row0 = blockIdx.x * TILE, col0 = blockIdx.y * TILE;
-    if (lower && col0 > row0 + TILE - 1) return;
+    __shared__ __attribute__((aligned(16))) double sX[BIG_DC][BIG_TR];
+    __shared__ __attribute__((aligned(16))) double sY[BIG_DC][BIG_TC];
+    const int row0 = blockIdx.x * BIG_TR, col0 = blockIdx.y * BIG_TC;
+    if (lower && col0 > row0 + BIG_TR - 1) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = row0 + 2 * tx;
-    const bool ok0 = r < n, ok1 = r + 1 < n;
+    const int r = row0 + 2 * tx;   // this lane's rows: r, r + 1, r + 64, r + 65
     // staging sources of this lane, clamped (rows / columns past the end are never stored)
-    const int xr = (row0 + lane < n) ? row0 + lane : n - 1;
+    const int xr0 = (row0 + lane < n) ? row0 + lane : n - 1;
+    const int xr1 = (row0 + 64 + lane < n) ? row0 + 64 + lane : n - 1;
     const int yc = (col0 + lane < m) ? col0 + lane : m - 1;
-    double s0[8], s1[8];
+    double acc[4][8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s0[q] = s1[q] = 0.0;
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[a][q] = 0.0;
     for (int d0 = 0; d0 < p.D; d0 += BIG_DC) {
         const int dc = (p.D - d0 < BIG_DC) ? p.D - d0 : BIG_DC;
         __syncthreads();  // the previous chunk has been consumed
 #pragma unroll
-        for (int k = 0; k < 2 * BIG_DC / 4; ++k) {
-            const int rowid = w + 4 * k;            // wave-uniform: operand = rowid >> 4, dimension = rowid & 15
-            const int dd = rowid & (BIG_DC - 1);
+        for (int k = 0; k < 3 * BIG_DC / 4; ++k) {
+            const int rowid = w + 4 * k;            // wave-uniform: part = rowid / 16 (X low, X high, Y), dimension = rowid % 16
+            const int dd = rowid & (BIG_DC - 1), part = rowid >> 4;
             if (dd < dc) {
                 const double ie = p.inv_ell[d0 + dd];
-                if (rowid < BIG_DC) sX[dd][lane] = __dmul_rn(X[(size_t)xr + (size_t)(d0 + dd) * ldx], ie);
+                if (part == 0) sX[dd][lane] = __dmul_rn(X[(size_t)xr0 + (size_t)(d0 + dd) * ldx], ie);
+                else if (part == 1) sX[dd][64 + lane] = __dmul_rn(X[(size_t)xr1 + (size_t)(d0 + dd) * ldx], ie);
                 else sY[dd][lane] = __dmul_rn(Y[(size_t)yc + (size_t)(d0 + dd) * ldy], ie);
             }
         }
         __syncthreads();
         for (int dd = 0; dd < dc; ++dd) {
-            const double2 xv = *reinterpret_cast<const double2 *>(&sX[dd][2 * tx]);
+            const double2 xa = *reinterpret_cast<const double2 *>(&sX[dd][2 * tx]);
+            const double2 xb = *reinterpret_cast<const double2 *>(&sX[dd][64 + 2 * tx]);
+            const double xv[4] = {xa.x, xa.y, xb.x, xb.y};
             const double2 *yp = reinterpret_cast<const double2 *>(&sY[dd][ty * 8]);
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2) {
                 const double2 yv = yp[q2];
-                const double a0 = __dsub_rn(xv.x, yv.x), a1 = __dsub_rn(xv.y, yv.x);
-                const double b0 = __dsub_rn(xv.x, yv.y), b1 = __dsub_rn(xv.y, yv.y);
-                s0[2 * q2] = fma(a0, a0, s0[2 * q2]);
-                s1[2 * q2] = fma(a1, a1, s1[2 * q2]);
-                s0[2 * q2 + 1] = fma(b0, b0, s0[2 * q2 + 1]);
-                s1[2 * q2 + 1] = fma(b1, b1, s1[2 * q2 + 1]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const double e0 = __dsub_rn(xv[a], yv.x), e1 = __dsub_rn(xv[a], yv.y);
+                    acc[a][2 * q2] = fma(e0, e0, acc[a][2 * q2]);
+                    acc[a][2 * q2 + 1] = fma(e1, e1, acc[a][2 * q2 + 1]);
+                }
             }
         }
     }
@@ -187,14 +196,21 @@ __global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X
     for (int q = 0; q < 8; ++q) {
         const int c = col0 + ty * 8 + q;
         if (c >= m) break;
-        double v0 = p.a2 * exp_nonpos(-0.5 * s0[q], ec), v1 = p.a2 * exp_nonpos(-0.5 * s1[q], ec);
-        if (same) {
-            if (r == c) v0 = p.a2 + diag_add;
-            if (r + 1 == c) v1 = p.a2 + diag_add;
+        double v[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ra = r + (a >> 1) * 64 + (a & 1);
+            v[a] = p.a2 * exp_nonpos(-0.5 * acc[a][q], ec);
+            if (same && ra == c) v[a] = p.a2 + diag_add;
         }
-        const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
-        if (vec & 2) store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, true);
-        else store_pair<false>(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rh = r + 64 * h;
+            const bool w0 = (rh < n) && (!lower || rh >= c), w1 = (rh + 1 < n) && (!lower || rh + 1 >= c);
+            double *dst = K + (size_t)rh + (size_t)c * ldk;
+            if (vec & 2) store_pair<true>(dst, v[2 * h], v[2 * h + 1], w0, w1, true);
+            else store_pair<false>(dst, v[2 * h], v[2 * h + 1], w0, w1, vec != 0);
+        }
     }
 }
 
@@ -449,18 +465,15 @@ void launch_se_cov(const gpmi_ctx *c, hipStream_t s, const double *dX, int n, in
     if (n <= 0 || m <= 0) return;
     const int same = (dY == nullptr);
     if (same) { dY = dX; ldy = ldx; }
-    dim3 grid((n + TILE - 1) / TILE, (m + TILE - 1) / TILE);
-    if (p.D <= GPMI_MAXD) grid = dim3((n + SE_TR - 1) / SE_TR, (m + SE_TC - 1) / SE_TC);  // k_se_cov<>
+    dim3 grid((n + BIG_TR - 1) / BIG_TR, (m + BIG_TC - 1) / BIG_TC);                      // k_se_cov_big
+    if (p.D <= 3) grid = dim3((n + SE_TR - 1) / SE_TR, (m + SE_TC - 1) / SE_TC);  // k_se_cov<D>
     const int vec = vec_ok(dK, ldk) ? (c->tune.se_nt ? 3 : 1) : 0;  // bit 1: non-temporal stores in k_se_cov<>
     switch (p.D) {
     case 1: hipLaunchKernelGGL(k_se_cov<1>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
     case 2: hipLaunchKernelGGL(k_se_cov<2>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
     case 3: hipLaunchKernelGGL(k_se_cov<3>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp); break;
-    default:
-        if (p.D <= GPMI_MAXD)
-            hipLaunchKernelGGL(k_se_cov<0>, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp);
-        else
-            hipLaunchKernelGGL(k_se_cov_big, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp);
+    default:  // measured at N = 16384: D = 8 0.45 ms through the register-resident generic form, 0.30 ms (D = 9) through this one
+        hipLaunchKernelGGL(k_se_cov_big, grid, 256, 0, s, dX, n, ldx, dY, m, ldy, p, diag_add, same, lower, dK, ldk, vec, h_exp);
         break;
     }
 }

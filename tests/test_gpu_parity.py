@@ -53,7 +53,8 @@ def test_probe_build_fragment_layout_and_variants(ctx):
         ctx.set_option("gemm_variant", 1)
 
 
-@pytest.mark.parametrize("n,m,D", [(1, 1, 1), (21, 21, 1), (64, 64, 3), (65, 130, 3), (200, 77, 2), (257, 300, 5), (130, 129, 8), (70, 33, 9), (40, 50, 20)])
+@pytest.mark.parametrize("n,m,D", [(1, 1, 1), (21, 21, 1), (64, 64, 3), (65, 130, 3), (200, 77, 2), (257, 300, 5), (130, 129, 8), (70, 33, 9), (40, 50, 20),
+                                   (100, 70, 64), (300, 200, 33), (129, 193, 17), (64, 64, 16), (65, 1, 48)])
 def test_se_cov_rect(ctx, orc, n, m, D):
     rng = np.random.default_rng(n * 1000 + m)
     X = rng.random((n, D)) * 3; Y = rng.random((m, D)) * 3
