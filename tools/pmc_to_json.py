@@ -25,5 +25,5 @@ for k, cs in acc.items():
     res[k] = e
 json.dump(res, open(out, "w"), indent=1)
 for k, e in res.items():
-    if "gemm" in k or "se_cov" in k or "potrf" in k or "trsm" in k:
+    if "gemm" in k or "se_cov" in k or "joint_cov" in k or "potrf" in k or "trsm" in k:
         print(k[:60], {x: ("%.4g" % y) for x, y in e.items() if x in ("hbm_bytes_per_launch", "mfma_util", "avg_us_profiled", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum")})
