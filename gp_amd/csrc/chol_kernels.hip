@@ -186,7 +186,7 @@ __device__ __forceinline__ double ld_blk(const double *p)
     if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
 }
-constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 16 * 17;  // doubles of workgroup memory the body needs (50 KB)
+constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 2 * 16 * 17;  // doubles of workgroup memory the body needs (52 KB)
 // COH: the block was written by other workgroups of the same launch with agent-scope stores; read it
 // with agent-scope loads (they do not trust this XCD's L2) instead of invalidating caches with a fence
 template <bool COH = false>
@@ -195,19 +195,26 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
 {
     double (*s_pub)[8][256] = reinterpret_cast<double (*)[8][256]>(sm);
     double (*s_inv)[256] = reinterpret_cast<double (*)[256]>(sm + 2 * 8 * 256);
-    double (*s_d16)[17] = reinterpret_cast<double (*)[17]>(sm + 2 * 8 * 256 + 8 * 256);
+    // the diagonal tile travels to the factor wave and comes back as L16 through s_d16[kb & 1]: two
+    // buffers, so that the owner of block-row kb + 1 can hand over the NEXT diagonal tile while the
+    // owner of block-row kb still reads L16 of this step
+    double (*s_d16)[16][17] = reinterpret_cast<double (*)[16][17]>(sm + 2 * 8 * 256 + 8 * 256);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
 
+    // TWO workgroup barriers per block column.  The chain factor16(kb) -> solve of block-row kb + 1 ->
+    // update of its diagonal tile -> factor16(kb + 1) crosses B2 and B1 only: the update of the next
+    // diagonal tile needs nothing but its owner's own solve result (register r of X is, lane for lane,
+    // the A and the B operand of X X^T), so no barrier stands between the solve and that update (the
+    // third barrier of the earlier form cost ~2 k of the ~7.7 k cycles per step).
     if (w == 3) {
 #pragma unroll 1
         for (int kb = 0; kb < 8; ++kb) {
-            __syncthreads();  // B1: the owner's diagonal tile is in s_d16
-            const int bad = factor16(s_d16, s_inv[kb], lane);
+            __syncthreads();  // B1: the owner's diagonal tile is in s_d16[kb & 1]; -X tiles of step kb - 1 published
+            const int bad = factor16(s_d16[kb & 1], s_inv[kb], lane);
             if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
-            __syncthreads();  // B2: L16 in s_d16, L16^-1 in s_inv
-            __syncthreads();  // B3: -X tiles published
+            __syncthreads();  // B2: L16 in s_d16[kb & 1], L16^-1 in s_inv[kb]
         }
         return;
     }
@@ -233,7 +240,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
 
 #define GPMI_SOLVE_ROW(T, NJ, br, X)                                                                   \
     if ((br) == kb) {                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) T[GPMI_CL(kb, NJ)][i] = s_d16[lr][lq + 4 * i];   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) T[GPMI_CL(kb, NJ)][i] = s_d16[kb & 1][lr][lq + 4 * i]; \
     } else if ((br) > kb) {                                                                            \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
             X = mfma(s_inv[kb][kg * 64 + lane], T[GPMI_CL(kb, NJ)][kg], X);                            \
@@ -249,13 +256,14 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     }
 
     // The only tile the next pivot block waits for is the diagonal tile of block-row kb + 1: its
-    // owner updates it first (EARLY) and hands it to the factor wave; every other update of step kb
-    // (REST) runs in the next iteration between B1 and B2, i.e. under the factor wave's 4.4 k cycles.
+    // owner updates it first (EARLY), straight from the registers of its own solve, and hands it to
+    // the factor wave; every other update of step kb (REST) runs in the next iteration between B1
+    // and B2, i.e. under the factor wave's 4.4 k cycles.
 #define GPMI_UPDATE_EARLY(T, NJ, br, X)                                                                \
     {                                                                                                  \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
-            T[GPMI_CL(kb + 1, NJ)] = mfma(s_pub[kb & 1][kb + 1][kg * 64 + lane], X[kg], T[GPMI_CL(kb + 1, NJ)]); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = T[GPMI_CL(kb + 1, NJ)][i]; \
+            T[GPMI_CL(kb + 1, NJ)] = mfma(-X[kg], X[kg], T[GPMI_CL(kb + 1, NJ)]);                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) s_d16[(kb + 1) & 1][lr][lq + 4 * i] = T[GPMI_CL(kb + 1, NJ)][i]; \
     }
 #define GPMI_UPDATE_REST(T, NJ, br, X)                                                                 \
     _Pragma("unroll") for (int jb = kb; jb < (NJ); ++jb) {                                             \
@@ -268,11 +276,11 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     d4 XA[8], XB[8], XC[8];
     if (rc == 0) {  // block-row 0 hands tile (0, 0) to the factor wave in matrix order
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_d16[lr][lq + 4 * i] = TC[0][i];
+        for (int i = 0; i < 4; ++i) s_d16[0][lr][lq + 4 * i] = TC[0][i];
     }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        __syncthreads();  // B1: diagonal tile kb is in s_d16
+        __syncthreads();  // B1: diagonal tile kb is in s_d16[kb & 1]; every wave's -X tiles of step kb - 1 are published
         if (kb > 0) {     // REST of step kb - 1: tiles jb >= kb of the rows below, except tile (kb, kb)
             if (ra >= kb) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
             if (rb >= kb) { GPMI_UPDATE_REST(TB, 5, rb, XB[kb - 1]) }
@@ -285,8 +293,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
         GPMI_SOLVE_ROW(TA, 8, ra, XA[kb])
         GPMI_SOLVE_ROW(TB, 5, rb, XB[kb])
         GPMI_SOLVE_ROW(TC, 2, rc, XC[kb])
-        __syncthreads();  // B3: -X tiles published
-        if (kb < 7) {     // EARLY: the next diagonal tile
+        if (kb < 7) {     // EARLY: the next diagonal tile (no barrier: own registers only)
             if (ra == kb + 1) GPMI_UPDATE_EARLY(TA, 8, ra, XA[kb])
             else if (rb == kb + 1) GPMI_UPDATE_EARLY(TB, 5, rb, XB[kb])
             else if (rc == kb + 1) GPMI_UPDATE_EARLY(TC, 2, rc, XC[kb])
@@ -1485,22 +1492,51 @@ __global__ void k_get_row(const double *__restrict__ W, size_t ld, int row, int 
     if (j < m) out[j] = scale * W[(size_t)row + (size_t)(col0 + j) * ld];
 }
 
-// sum log L_ii, z'z (z = row zrow of the factor), logml; one workgroup, fixed order
-__global__ __launch_bounds__(1024) void k_logml_finalize(const double *__restrict__ W, size_t ld, int n,
-                                                         int zrow, const int *d_info,
-                                                         double *__restrict__ out3, int *info_out)
+// sum log L_ii, z'z (z = row zrow of the factor), logml.  Two launches with a fixed shape (the sums do
+// not depend on timing): FIN_WG workgroups reduce 256-element slices of the diagonal -- every L_ii
+// sits in a cache line of its own, so the loads want many waves in flight; one workgroup doing all of
+// them took 60 us at N = 16384 -- and a last workgroup adds the slice sums in slice order.
+constexpr int FIN_SLICE = 256;
+__global__ __launch_bounds__(FIN_SLICE) void k_logml_partial(const double *__restrict__ W, size_t ld, int n, int zrow,
+                                                             double *__restrict__ part)
 {
-    __shared__ double s_a[1024], s_b[1024];
+    __shared__ double s_a[FIN_SLICE], s_b[FIN_SLICE];
+    const int i = blockIdx.x * FIN_SLICE + threadIdx.x;
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        a += log(W[(size_t)i * (ld + 1)]);
+    if (i < n) {
+        a = log(W[(size_t)i * (ld + 1)]);
         const double z = W[(size_t)zrow + (size_t)i * ld];
-        b = fma(z, z, b);
+        b = z * z;
     }
     s_a[threadIdx.x] = a;
     s_b[threadIdx.x] = b;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
+    for (int s = FIN_SLICE / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_a[threadIdx.x] += s_a[threadIdx.x + s];
+            s_b[threadIdx.x] += s_b[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = s_a[0];
+        part[2 * blockIdx.x + 1] = s_b[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_logml_finalize(const double *__restrict__ part, int nslice, int n,
+                                                        const int *d_info, double *__restrict__ out3, int *info_out)
+{
+    __shared__ double s_a[256], s_b[256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nslice; i += 256) {
+        a += part[2 * i];
+        b += part[2 * i + 1];
+    }
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
             s_a[threadIdx.x] += s_a[threadIdx.x + s];
             s_b[threadIdx.x] += s_b[threadIdx.x + s];
@@ -1594,7 +1630,7 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->syrk_order = 0;
     t->stagger = (2 << 16) | 4;
     t->fuse_diag = 7;
-    t->diag_waves = 5;
+    t->diag_waves = 4;
     t->nb_adapt = 0;
     t->ksplit = 1;
     t->ksplit_max = 100;
@@ -1663,7 +1699,8 @@ static bool launch_gemm_nt_fused(const gpmi_ctx *c, hipStream_t s, const double 
     return true;
 }
 
-// tune.diag_waves  5: k_potrf_diag (4 tile waves + factor wave), 4: k_potrf_diag4 (fits beside a resident SYRK workgroup)
+// tune.diag_waves  4 (default): k_potrf_diag4 (3 tile waves + factor wave, two barriers per block column; fits beside a
+//                  resident SYRK workgroup), 5: k_potrf_diag (4 tile waves + factor wave, three barriers)
 // tune.nb_adapt    1: auto outer-block width chosen per block from the columns still to factor (measured: -0.2 ms
 //                  sequential at N = 16384, nothing with lanes)
 // tune.ksplit      quadrant split of the tail-round tiles of a SYRK launch (see KSplit) ...
@@ -2045,10 +2082,13 @@ void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0
     hipLaunchKernelGGL(k_get_row, dim3((m + 255) / 256), 256, 0, s, W, ld, row, col0, m, scale, out);
 }
 
+// part: 2 * ceil(n / 256) doubles of scratch
 void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
-                           const int *d_info, double *d_out3, int *d_info_out)
+                           const int *d_info, double *d_out3, int *d_info_out, double *part)
 {
-    hipLaunchKernelGGL(k_logml_finalize, dim3(1), 1024, 0, s, W, ld, n, zrow, d_info, d_out3, d_info_out);
+    const int nslice = (n + FIN_SLICE - 1) / FIN_SLICE;
+    hipLaunchKernelGGL(k_logml_partial, dim3(nslice), FIN_SLICE, 0, s, W, ld, n, zrow, part);
+    hipLaunchKernelGGL(k_logml_finalize, dim3(1), 256, 0, s, part, nslice, n, d_info, d_out3, d_info_out);
 }
 
 int trmv_lower_chunks(int n) { return (n + TMV_COLS - 1) / TMV_COLS; }

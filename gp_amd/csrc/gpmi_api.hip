@@ -250,6 +250,7 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
     HIPCHK(hipStreamSynchronize(c->own_stream));
     c->ncu = prop.multiProcessorCount;
     HIPCHK(hipMalloc((void **)&c->d_out, 64));
+    HIPCHK(hipMalloc((void **)&c->d_fin, 65536));  // slice sums of the finalize kernels: 2 doubles per 256 rows
     for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
     *out = c;
     return 0;
@@ -270,6 +271,7 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         hipFree(c->itp_part);
         free(c->itp_lp);
         hipFree(c->d_out);
+        hipFree(c->d_fin);
         hipFree(c->scratch);
         for (int i = 0; i < 4; ++i) {
             hipFree(c->stage[i]);
@@ -801,7 +803,7 @@ static int logml_core(gpmi_ctx *c, const double *dX, int n, int ldx, const doubl
     tic(c, 1);
     if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, nullptr))) return rc;
     tic(c, 2);
-    launch_logml_finalize(c->stream, c->W, ld, n, n, c->d_info, d_out3, d_info);
+    launch_logml_finalize(c->stream, c->W, ld, n, n, c->d_info, d_out3, d_info, c->d_fin);
     tic(c, 3);
     HIPCHK(hipGetLastError());
     return 0;
@@ -923,7 +925,7 @@ extern "C" int gpmi_joint_logml_dev(gpmi_ctx *c, const double *dt, int n, const 
     tic(c, 1);
     if ((rc = launch_potrf_partial(c, c->W, ld, M, n2, n2, c->d_info, nullptr))) return rc;
     tic(c, 2);
-    launch_logml_finalize(c->stream, c->W, ld, n2, n2, c->d_info, d_out3, d_info);
+    launch_logml_finalize(c->stream, c->W, ld, n2, n2, c->d_info, d_out3, d_info, c->d_fin);
     tic(c, 3);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1388,7 +1390,7 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     launch_se_cov(c, s, dX, n, n, nullptr, n, n, p, sigma * sigma + jitter, 1, c->W, ld);
     launch_set_row(s, c->W, ld, n, dy, n, n);
     if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, Fall))) return rc;
-    launch_logml_finalize(s, c->W, ld, n, n, c->d_info, c->d_out, c->d_info + 1);
+    launch_logml_finalize(s, c->W, ld, n, n, c->d_info, c->d_out, c->d_info + 1, c->d_fin);
     launch_get_row(s, c->W, ld, n, 0, n, 1.0, zv);
     // U = L^-T, a = U z = K^-1 y
     hipLaunchKernelGGL(k_set_identity, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, ldu, n);

@@ -24,7 +24,7 @@ struct gpmi_tuning {
     int syrk_order;       // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
     int stagger;          // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup of a CU pair
     int fuse_diag;        // bit 0: in-block GEMMs, bit 1: trailing SYRK, bit 2: sub-tiled diagonal tile
-    int diag_waves;       // 5: k_potrf_diag, 4: k_potrf_diag4
+    int diag_waves;       // 4: k_potrf_diag4 (default), 5: k_potrf_diag
     int nb_adapt;
     int ksplit, ksplit_max;
     int block_recursive;
@@ -51,6 +51,7 @@ struct gpmi_ctx {
                              // [8] sub-tile counter of the fused in-block GEMM
     int ncu;                 // compute units of the device
     double *d_out;           // 3 doubles
+    double *d_fin;           // slice sums of the finalize kernels
     // generic device staging buffers for the host-pointer API
     double *stage[4];
     size_t stage_bytes[4];
@@ -141,7 +142,7 @@ void launch_syrk_uut(const gpmi_ctx *c, hipStream_t s, const double *U, size_t l
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all);
 void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0, int m, double scale, double *out);
 void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
-                           const int *d_info, double *d_out3, int *d_info_out);
+                           const int *d_info, double *d_out3, int *d_info_out, double *part /* 2 ceil(n/256) doubles */);
 int trmv_lower_chunks(int n);
 void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *z, double *f,
                        double *part /* trmv_lower_chunks(n) * n doubles */);

@@ -130,13 +130,13 @@ def test_options_do_not_change_results_beyond_rounding(ctx, orc):
     base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     vals = []
     for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("lookahead", 1), ("lookahead", 0), ("syrk_order", 1),
-                   ("diag_waves", 4), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 1)):
+                   ("diag_waves", 5), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 1)):
         ctx.set_option(opt, v)
         try:
             vals.append(ctx.logml(X, y, 1.0, [0.3], 0.1)[0])
         finally:
             ctx.set_option("nb_outer", 0); ctx.set_option("lookahead", -1); ctx.set_option("syrk_order", 0)
-            ctx.set_option("diag_waves", 5); ctx.set_option("ksplit", 1); ctx.set_option("stagger", (2 << 16) | 4)
+            ctx.set_option("diag_waves", 4); ctx.set_option("ksplit", 1); ctx.set_option("stagger", (2 << 16) | 4)
             ctx.set_option("se_nt", 1); ctx.set_option("nb_adapt", 0)
     assert all(abs(v - base) <= 1e-10 * abs(base) for v in vals), (base, vals)
 
