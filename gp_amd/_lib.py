@@ -22,14 +22,14 @@ SYMBOLS = (
     "gpmi_se_cov", "gpmi_se_cov_dev", "gpmi_deriv_cov", "gpmi_deriv_cov_dev", "gpmi_deriv_elem",
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
-    "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition",
+    "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition", "gpmi_sample_derivs", "gpmi_sample_derivs_batch",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
     "gpmi_interp_free", "gpmi_logml_grad",
     "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
     "gpmi_last_timing", "gpmi_kernel_timing",
 )
 # additionally exported by the probe build (libgpmi_probes.so, -DGPMI_PROBES; tools/ only)
-PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock")
+PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock", "gpmi_probe_fused")
 
 
 class GpmiError(RuntimeError):
@@ -357,6 +357,32 @@ class Context:
                                          max(m, 1)))
         return mn, Kn
 
+    def sample_derivs(self, t, ts, y, l, a, sy, jitter, z):
+        """(draw, mu): mu + chol(cov) z of sample_derivs (pendulum_fit.R:227-255), fused on the device."""
+        t = _vec(t); ts = _vec(ts); y = _vec(y); z = _vec(z)
+        if y.size != t.size or z.size != ts.size:
+            raise GpmiError(-1, "y must match t and z must match ts")
+        draw = np.empty(ts.size); mu = np.empty(ts.size)
+        _chk(self._lib.gpmi_sample_derivs(self._h, _p(t), int(t.size), _p(ts), int(ts.size), _p(y), _d(l), _d(a), _d(sy),
+                                          _d(jitter), _p(z), _p(draw), _p(mu)))
+        return draw, mu
+
+    def sample_derivs_batch(self, t, ts, Y, params, jitter, Z):
+        """(draws (m, B), mus (m, B), info (B,)): B independent draws on the lanes; Y (n, B), params (B, 3) rows
+        (l, a, sy), Z (m, B)."""
+        t = _vec(t); ts = _vec(ts)
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64).reshape(t.size, -1))
+        B = Y.shape[1]
+        Z = np.asfortranarray(np.asarray(Z, dtype=np.float64).reshape(ts.size, -1))
+        P = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(-1, 3))
+        if Z.shape[1] != B or P.shape[0] != B:
+            raise GpmiError(-1, "Y, params and Z disagree on the batch size")
+        draws = np.empty((ts.size, B), order="F"); mus = np.empty((ts.size, B), order="F"); info = np.zeros(B, dtype=np.int32)
+        _chk(self._lib.gpmi_sample_derivs_batch(self._h, _p(t), int(t.size), _p(ts), int(ts.size), _p(Y), max(int(t.size), 1),
+                                                _p(P), B, _d(jitter), _p(Z), max(int(ts.size), 1), _p(draws), max(int(ts.size), 1),
+                                                _p(mus), max(int(ts.size), 1), _p(info)))
+        return draws, mus, info
+
     def seq_sampler(self, X, mn, Kn, alpha, ell, jitter=1e-6, max_steps=256):
         """Sequential conditional sampler (create_p_dotXnS, R/ode_gp_library.R:43-93)."""
         return SeqSampler(self, X, mn, Kn, alpha, ell, jitter, max_steps)
@@ -413,6 +439,11 @@ class Context:
         if out[2] == 0:
             return 0.0, 0.0, 0
         return out[0] / max(out[1], 1.0) * 100.0, out[0] / out[2], int(out[2])
+
+    def probe_fused(self):
+        out = np.zeros(5)
+        _chk(self._probe("gpmi_probe_fused")(self._h, _p(out)))
+        return out
 
     def probe_mfma_peak(self, iters=20000):
         t = C.c_double(0.0); mhz = C.c_double(0.0)

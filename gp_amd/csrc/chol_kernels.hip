@@ -924,6 +924,7 @@ struct KSplit {
 // shader-clock probe: per workgroup of the SYRK kernel, elapsed shader cycles (s_memtime) and elapsed
 // 100 MHz reference ticks (s_memrealtime), summed over the launch -> average clock and cycles per tile
 __device__ unsigned long long g_clk[4];
+__device__ unsigned long long g_fz[8];  // fused in-block launch, block 0: cycles in sub-tile, flag wait, diagonal body; launches
 #endif
 
 template <int MODE>
@@ -988,6 +989,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         // waits for the other two and factors the block.  Blocks >= 3 are the tiles 1, 2, ...
         const int b = blockIdx.x;
         if (b < 3) {
+#ifdef GPMI_PROBES
+            const unsigned long long fz0 = __builtin_amdgcn_s_memtime();
+#endif
             gemm_sub64<true>(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0, GT, GT);
             // the agent-scope stores above are complete (acknowledged by the memory side) once
             // vmcnt drains; no cache-wide fence is needed around this hand-over
@@ -997,13 +1001,28 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
                 if (threadIdx.x == 0) atomicAdd(fd.ctr, 1);
                 return;
             }
+#ifdef GPMI_PROBES
+            const unsigned long long fz1 = __builtin_amdgcn_s_memtime();
+#endif
             if (threadIdx.x == 0) {
                 while (__hip_atomic_load(fd.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2)
                     __builtin_amdgcn_s_sleep(4);
                 __hip_atomic_store(fd.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
             }
             __syncthreads();
+#ifdef GPMI_PROBES
+            const unsigned long long fz2 = __builtin_amdgcn_s_memtime();
+#endif
             potrf_diag4_body<true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+#ifdef GPMI_PROBES
+            if (threadIdx.x == 0) {
+                atomicAdd(&g_fz[0], fz1 - fz0);
+                atomicAdd(&g_fz[1], fz2 - fz1);
+                atomicAdd(&g_fz[2], __builtin_amdgcn_s_memtime() - fz2);
+                atomicAdd(&g_fz[3], 1ull);
+                atomicAdd(&g_fz[4], (unsigned long long)K);
+            }
+#endif
             return;
         }
         const int gx = (M + GT - 1) / GT;
@@ -2103,6 +2122,14 @@ void launch_trmv_lower(hipStream_t s, const double *L, size_t ldl, int n, const 
 }
 
 #ifdef GPMI_PROBES
+int probe_fused_read(hipStream_t s, unsigned long long *out5)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_fz), 5 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fz), z, sizeof z) != hipSuccess;
+}
+
 int probe_clock_read(hipStream_t s, int reset, unsigned long long *out3)
 {
     unsigned long long h[4] = {0, 0, 0, 0};

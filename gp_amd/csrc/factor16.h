@@ -23,6 +23,23 @@ __device__ __forceinline__ double bcast16(double v)
     return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true);
 }
 
+// acc += -(value of `src` in lane J of each 16-lane row) * own, in ONE instruction: v_fmac_f64 is a VOP2
+// instruction and takes a DPP row broadcast on its first source (gfx90a+ "DP ALU DPP"), where the
+// compiler emits v_mov_b64_dpp + v_fma_f64 -- a dependent pair per update, and these updates are most
+// of what the single, in-order factor wave issues per pivot.  The rounding is that of
+// fma(-bcast(src), own, acc).  NOP1: the hardware does not interlock a DPP read of a VGPR the
+// preceding VALU instruction wrote (2 wait states on gfx9); the hazard recogniser cannot see into
+// inline assembly, so the first use after `src` was produced carries its own s_nop (the statements are
+// volatile: they keep their program order, the later ones of a group stay behind the first).
+template <int J, bool NOP1 = false>
+__device__ __forceinline__ void fnmac_bcast16(double &acc, double src, double own)
+{
+    if constexpr (NOP1)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(J));
+    else
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own), "n"(J));
+}
+
 // Cholesky of a 16x16 SPD tile held in LDS as [row][col] (lower triangle used) and the
 // inverse of its factor.  One wave; every lane keeps matrix row lane&15 in registers (the four
 // 16-lane DPP rows hold identical copies of the factor), pivots and multipliers travel by DPP
@@ -61,7 +78,7 @@ __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int 
         const double cj = row[j] * ri;
         static_for<j + 1, 16>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            row[c] = fma(-cj, bcast16<c>(cj), row[c]);  // L[c][j] lives in lane c
+            fnmac_bcast16<c, c == j + 1>(row[c], cj, cj);  // row[c] -= L[c][j] (lives in lane c) * L[r][j]
         });
         double s = d * ri;
         s = fma(0.5 * ri, fma(-s, s, d), s);
@@ -71,11 +88,10 @@ __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int 
         // Inverse, step j: row j of Y is final (acc_j / L_jj), is broadcast from lane j of each
         // DPP row, and every lane r > j subtracts L[r][j] * Y[j][:].  Columns past j are still
         // zero in lane j, so the registers i > j/4 need no work.
-        const double m = (lrj > j) ? cj : 0.0;
+        const double m = (lrj > j) ? cj * dinv : 0.0;  // L[r][j] / L_jj below the pivot, 0 on and above it
         static_for<0, j / 4 + 1>([&](auto ic_) {
             constexpr int i = decltype(ic_)::value;
-            const double y = bcast16<j>(acc[i]) * dinv;
-            acc[i] = fma(-m, y, acc[i]);
+            fnmac_bcast16<j, i == 0>(acc[i], acc[i], m);  // acc[i] -= (acc[i] of lane j) * m; lane j itself: m = 0
         });
     });
     // first row whose pivot was not a positive finite number (lanes 0..15 hold rows 0..15)

@@ -426,7 +426,14 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
 // alias HBM channels and 16-column slack exists past the end for tile over-reads
 static int reserve_ws(gpmi_ctx *c, int rows, int cols)
 {
-    const int ld = ((rows + 15) / 16) * 16 + 16;
+    int ld = ((rows + 15) / 16) * 16 + 16;
+#ifdef GPMI_PROBES
+    if (const char *e = getenv("GPMI_LD")) {  // experiment: force the leading dimension (>= the natural one)
+        const int v = atoi(e);
+        if (v >= ld) ld = v;
+    }
+    if (const char *e = getenv("GPMI_LD_PAD")) ld += atoi(e);
+#endif
     const size_t need = ((size_t)ld * (size_t)(cols + 1) + 4096) * sizeof(double);
     if (need > c->W_bytes) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1474,6 +1481,141 @@ extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const doub
     return info;
 }
 
+// ---- sample_derivs: one draw of the derivative process, fused on the device --------------------
+// pendulum_fit.R:227-255 (lorenz.Rmd:80-107 with separate prediction times): K = a^2 QQ(ti, ti),
+// KsK = a^2 RQ(tis, ti), KsKs = a^2 RR(tis, tis); mu = KsK (K + sy^2 I)^-1 y (:242-245);
+// cov = KsKs - KsK (K + sy^2 I)^-1 t(KsK) + jitter I (:247-251); one draw mvrnorm(1, mu, cov) (:253).
+// Here: the augmented partial factorisation of gpmi_gp_condition leaves cov as the trailing block of the
+// workspace; it is factored IN PLACE and the draw is mu + chol(cov) z -- the m x m covariance (537 MB at
+// m = 8192) never crosses PCIe, where the host-side composition potrf(gp_condition(...)) moved it three
+// times.  MASS::mvrnorm draws through an eigen-decomposition with R's (unseeded) RNG: the moments are the
+// parity surface, the standard-normal variate z is the caller's.
+namespace {
+__global__ void k_axpy1(double *__restrict__ y, const double *__restrict__ x, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+// status of one draw from the two device infos: K + sy^2 I not PD -> its order k (1..n); cov not PD -> n + k
+__global__ void k_merge_info(const int *__restrict__ a, const int *__restrict__ b, int n, int *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = a[0] ? a[0] : (b[0] ? n + b[0] : 0);
+}
+}  // namespace
+
+// every buffer sample_derivs_core(c, n, m) touches, at its final size (a growing buffer synchronises its stream)
+static int sample_derivs_reserve(gpmi_ctx *c, int n, int m)
+{
+    int rc;
+    if ((rc = reserve_ws(c, n + m + 1, n + m))) return rc;
+    double *b;
+    return stage_buf(c, 3, ((size_t)trmv_lower_chunks(m) + 1) * m * sizeof(double), &b);
+}
+
+// all pointers device; ddraw, dmu: m doubles; d_status: 1 int; enqueues on c->stream, no synchronisation
+static int sample_derivs_core(gpmi_ctx *c, const double *dt, int n, const double *dts, int m, const double *dy,
+                              double a, double l, double s2, double jitter, const double *dz, double *ddraw, double *dmu,
+                              int *d_status)
+{
+    int rc;
+    const int nt = n + m, M = nt + 1;
+    if ((rc = sample_derivs_reserve(c, n, m))) return rc;
+    const size_t ld = (size_t)c->ld;
+    hipStream_t s = c->stream;
+    double *part = c->stage[3];
+    HIPCHK(hipMemsetAsync(c->d_info, 0, 4 * sizeof(int), s));
+    const double a2 = a * a;
+    launch_deriv_cov(s, GPMI_QQ, dt, n, dt, n, a2, l, 0, 1, c->W, ld);
+    launch_add_diag(s, c->W, ld, n, s2);
+    launch_deriv_cov(s, GPMI_RQ, dts, m, dt, n, a2, l, 0, 0, c->W + n, ld);
+    launch_deriv_cov(s, GPMI_RR, dts, m, dts, m, a2, l, 0, 1, c->W + n + (size_t)n * ld, ld);
+    launch_set_row(s, c->W, ld, nt, dy, n, nt);
+    if ((rc = launch_potrf_partial(c, c->W, ld, M, nt, n, c->d_info, nullptr))) return rc;
+    double *S = c->W + n + (size_t)n * ld;     // Schur complement = cov - jitter I (lower), rows n .. nt - 1
+    launch_add_diag(s, S, ld, m, jitter);
+    launch_get_row(s, c->W, ld, nt, n, m, -1.0, dmu);  // last row of the trailing block: -mu^T
+    if ((rc = launch_potrf_partial(c, S, ld, m, m, m, c->d_info + 2, nullptr))) return rc;
+    launch_trmv_lower(s, S, ld, m, dz, ddraw, part);
+    hipLaunchKernelGGL(k_axpy1, dim3((m + 255) / 256), 256, 0, s, ddraw, dmu, m);
+    hipLaunchKernelGGL(k_merge_info, dim3(1), 64, 0, s, c->d_info, c->d_info + 2, n, d_status);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_sample_derivs(gpmi_ctx *c, const double *t, int n, const double *ts, int m, const double *y,
+                                  double l, double a, double sy, double jitter, const double *z, double *draw, double *mu)
+{
+    ENTER(c);
+    if (n <= 0 || m <= 0 || !t || !ts || !y || !z || !draw || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    double *d;
+    if ((rc = sample_derivs_reserve(c, n, m))) return rc;
+    if ((rc = stage_buf(c, 0, ((size_t)2 * n + 4 * (size_t)m + 8) * sizeof(double), &d))) return rc;
+    double *dt = d, *dy = d + n, *dts = dy + n, *dz = dts + m, *ddraw = dz + m, *dmu = ddraw + m;
+    int *dst = (int *)(dmu + m);
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dts, ts, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dz, z, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = sample_derivs_core(c, dt, n, dts, m, dy, a, l, sy * sy, jitter, dz, ddraw, dmu, dst))) return rc;
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(draw, ddraw, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (mu) HIPCHK(hipMemcpyAsync(mu, dmu, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&st, dst, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return st;
+}
+
+// B independent draws, draw b from (params[3 b .. 3 b + 2] = (l, a, sy), Y[:, b], Z[:, b]): the loop
+// mclapply(s_list[1:100], sample_derivs_both_states, mc.cores = 2) of pendulum_fit.R:261-268 -- one posterior
+// draw of the hyper-parameters and one noisy series per call -- as concurrent conditionings on the lanes.
+extern "C" int gpmi_sample_derivs_batch(gpmi_ctx *c, const double *t, int n, const double *ts, int m, const double *Y, int ldy,
+                                        const double *params, int B, double jitter, const double *Z, int ldz, double *draws,
+                                        int ldd, double *mus, int ldmu, int *info)
+{
+    ENTER(c);
+    if (B < 0) return gpmi_fail(GPMI_EARG, "negative batch size");
+    if (B == 0) return 0;
+    if (n <= 0 || m <= 0 || !t || !ts || !Y || !params || !Z || !draws || !info || ldy < n || ldz < m || ldd < m || (mus && ldmu < m))
+        return gpmi_fail(GPMI_EARG, "bad argument");
+    for (int b = 0; b < B; ++b)
+        if (!(params[3 * b] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
+    int rc;
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
+    if (lanes > 8) lanes = 8;
+    if (lanes > B) lanes = B;
+    if ((rc = lanes_prepare(c, lanes))) return rc;
+    for (int l = 0; l < lanes; ++l)
+        if ((rc = sample_derivs_reserve(l ? c->lane[l - 1] : c, n, m))) return rc;
+    double *d;
+    const size_t nb = (size_t)n * B, mb = (size_t)m * B;
+    if ((rc = stage_buf(c, 0, ((size_t)n + m + nb + 3 * mb + B + 8) * sizeof(double), &d))) return rc;
+    double *dt = d, *dts = dt + n, *dY = dts + m, *dZ = dY + nb, *dD = dZ + mb, *dM = dD + mb;
+    int *dst = (int *)(dM + mb);
+    hipStream_t const caller = c->stream;
+    HIPCHK(hipMemcpyAsync(dt, t, (size_t)n * sizeof(double), hipMemcpyHostToDevice, caller));
+    HIPCHK(hipMemcpyAsync(dts, ts, (size_t)m * sizeof(double), hipMemcpyHostToDevice, caller));
+    HIPCHK(hipMemcpy2DAsync(dY, (size_t)n * sizeof(double), Y, (size_t)ldy * sizeof(double), (size_t)n * sizeof(double), B, hipMemcpyHostToDevice, caller));
+    HIPCHK(hipMemcpy2DAsync(dZ, (size_t)m * sizeof(double), Z, (size_t)ldz * sizeof(double), (size_t)m * sizeof(double), B, hipMemcpyHostToDevice, caller));
+    const int la_saved = c->lookahead;
+    lanes_fork(c, lanes, caller);
+    for (int b = 0; b < B && !rc; ++b) {
+        gpmi_ctx *lc = (b % lanes == 0) ? c : c->lane[b % lanes - 1];
+        const double l = params[3 * b], a = params[3 * b + 1], sy = params[3 * b + 2];
+        rc = sample_derivs_core(lc, dt, n, dts, m, dY + (size_t)b * n, a, l, sy * sy, jitter, dZ + (size_t)b * m, dD + (size_t)b * m,
+                                dM + (size_t)b * m, dst + b);
+    }
+    lanes_join(c, lanes, caller, la_saved);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy2DAsync(draws, (size_t)ldd * sizeof(double), dD, (size_t)m * sizeof(double), (size_t)m * sizeof(double), B, hipMemcpyDeviceToHost, caller));
+    if (mus) HIPCHK(hipMemcpy2DAsync(mus, (size_t)ldmu * sizeof(double), dM, (size_t)m * sizeof(double), (size_t)m * sizeof(double), B, hipMemcpyDeviceToHost, caller));
+    HIPCHK(hipMemcpyAsync(info, dst, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, caller));
+    HIPCHK(hipStreamSynchronize(caller));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- sequential conditional sampler -------------------------------------
 // create_p_dotXnS, R/ode_gp_library.R:43-93.  The reference re-derives, at every call, the joint
 // mean and covariance of ALL star points so far,
@@ -1884,6 +2026,18 @@ extern "C" int gpmi_probe_syrk(gpmi_ctx *c, int m, int k, int reps, double *ms)
     float t = 0.f;
     HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
     *ms = t / reps;
+    return 0;
+}
+
+int probe_fused_read(hipStream_t s, unsigned long long *out5);
+// out5: block 0 of the fused in-block launches since the last call: cycles in its 64 x 64 sub-tile, in the
+// wait for the other two sub-tiles, in the diagonal-block body; launches; sum of K
+extern "C" int gpmi_probe_fused(gpmi_ctx *c, double *out5)
+{
+    ENTER(c);
+    unsigned long long h[5];
+    if (probe_fused_read(c->stream, h)) return gpmi_fail(GPMI_EHIP, "probe read failed");
+    for (int i = 0; i < 5; ++i) out5[i] = (double)h[i];
     return 0;
 }
 

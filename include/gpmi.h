@@ -225,6 +225,24 @@ GPMI_API int gpmi_gp_condition(gpmi_ctx *ctx, const double *t, int n, const doub
                       const double *y, double alpha, double l, double s2, double jitter,
                       int kindK, int kindS, int kindSS, int flags, double *mn, double *Kn, int ldkn);
 
+/* One draw of the derivative process given noisy values: sample_derivs(params = (l, a, sy), ynoise, ti),
+ * pendulum_fit.R:227-255 (separate prediction times ts: lorenz.Rmd:80-107, jitter 1e-6 there, 1e-8 here):
+ * draw = mu + chol(cov) z with the (QQ, RQ, RR) moments of gpmi_gp_condition, fused on the device -- the
+ * m x m covariance is factored in place in the workspace and never crosses PCIe.  The reference draws
+ * with MASS::mvrnorm and R's unseeded RNG, so the standard-normal variate z (m doubles) is the caller's;
+ * mu (nullable) receives the mean.  Status k in 1..n: K + sy^2 I is not positive definite at order k;
+ * n + k: the posterior covariance is not (at order k). */
+GPMI_API int gpmi_sample_derivs(gpmi_ctx *ctx, const double *t, int n, const double *ts, int m, const double *y,
+                                double l, double a, double sy, double jitter, const double *z, double *draw, double *mu);
+/* B independent draws -- the loop mclapply(s_list[1:100], sample_derivs_both_states, mc.cores = 2) of
+ * pendulum_fit.R:261-268 (one posterior draw of (l, a, sy) and one noisy series per call) -- run as
+ * concurrent conditionings on the context's lanes.  params: 3 x B (l, a, sy per draw); Y: n x B, Z: m x B,
+ * draws: m x B, mus (nullable): m x B, column-major with the given leading dimensions; info[b] as the
+ * status of gpmi_sample_derivs (a failed draw does not stop the others). */
+GPMI_API int gpmi_sample_derivs_batch(gpmi_ctx *ctx, const double *t, int n, const double *ts, int m, const double *Y,
+                                      int ldy, const double *params, int B, double jitter, const double *Z, int ldz,
+                                      double *draws, int ldd, double *mus, int ldmu, int *info);
+
 /* ---- sequential conditional sampler ------------------------------------ */
 
 /* create_p_dotXnS(Xn_list, mn, Kn, theta), R/ode_gp_library.R:43-93 (R/tests.R:78-91): a stateful
@@ -273,6 +291,10 @@ GPMI_API int gpmi_probe_syrk(gpmi_ctx *ctx, int m, int k, int reps, double *ms);
 /* Shader-clock probe of the SYRK kernel: out3 = summed shader cycles, summed 100 MHz ticks and number of
  * workgroups of every trailing-update launch since the last reset. */
 GPMI_API int gpmi_probe_clock(gpmi_ctx *ctx, int reset, double *out3);
+
+/* Fused in-block launches since the last call, block 0: cycles in the sub-tile product, in the wait for the
+ * other two sub-tiles, in the diagonal-block body; number of launches; sum of their K. */
+GPMI_API int gpmi_probe_fused(gpmi_ctx *ctx, double *out5);
 
 /* MFMA f64 fragment-layout probe: D = A(16x4) * B(4x16) on one wave with the
  * library's fragment conventions; out256 row-major D[i][j].  Host buffers. */

@@ -38,12 +38,22 @@ gpmi_derivative_kernels_env <- local({
   # matrix-level fast path for a^2 * outer(ti, ti, FUN = kern_fixed_l(kern, l)), pendulum_fit.R:237-240
   se_deriv_cov <- function(t1, t2, l, alpha, block) .Call("gpmi_R_deriv_cov", .gpmi_kinds[[block]], as.double(t1),
                                                           as.double(t2), alpha, l, 0L)
-  # sample_derivs(params, ynoise, ti): pendulum_fit.R:227-255 with ONE Cholesky on the GPU
-  sample_derivs <- function(params, ynoise, ti) {
-    r <- .Call("gpmi_R_gp_condition", as.double(ti), as.double(ti), as.double(ynoise), params[2], params[1],
-               params[3]^2, 1e-8, c(0L, 2L, 3L), 0L)
-    MASS::mvrnorm(1, as.numeric(r[[1]]), r[[2]])
+  # sample_derivs(params, ynoise, ti): pendulum_fit.R:227-255, params = c(l, a, sy).  One draw mu + chol(cov) z, fused
+  # on the GPU (the N x N covariance never leaves the device); z from R's RNG
+  sample_derivs <- function(params, ynoise, ti, tis = ti, jitter = 1e-8)
+    .Call("gpmi_R_sample_derivs", as.double(ti), as.double(tis), as.double(ynoise), as.double(params[1:3]), jitter,
+          rnorm(length(tis)))
+  # the mclapply(s_list[1:100], sample_derivs_both_states, mc.cores = 2) loop of pendulum_fit.R:261-268 as ONE call:
+  # params_list: list of c(l, a, sy); ynoise_list: list of series -> matrix of draws, one column each
+  sample_derivs_many <- function(params_list, ynoise_list, ti, tis = ti, jitter = 1e-8) {
+    B <- length(params_list)
+    .Call("gpmi_R_sample_derivs_batch", as.double(ti), as.double(tis), do.call(cbind, lapply(ynoise_list, as.double)),
+          do.call(cbind, lapply(params_list, function(p) as.double(p[1:3]))), jitter, matrix(rnorm(length(tis) * B), ncol = B))
   }
+  # moments only (mu, cov), as in round 1
+  sample_derivs_moments <- function(params, ynoise, ti, tis = ti, jitter = 1e-8)
+    .Call("gpmi_R_gp_condition", as.double(ti), as.double(tis), as.double(ynoise), params[2], params[1],
+          params[3]^2, jitter, c(0L, 2L, 3L), 0L)
   environment()
 })
 

@@ -206,6 +206,35 @@ SEXP gpmi_R_gp_condition(SEXP t, SEXP ts, SEXP y, SEXP alpha, SEXP l, SEXP s2, S
     return out;
 }
 
+/* sample_derivs(params, ynoise, ti): pendulum_fit.R:227-255, one draw mu + chol(cov) z fused on the device; z = rnorm(m)
+ * comes from R's own RNG (the reference's MASS::mvrnorm stream cannot be reproduced: eigen-decomposition draw) */
+SEXP gpmi_R_sample_derivs(SEXP t, SEXP ts, SEXP y, SEXP params, SEXP jitter, SEXP z)
+{
+    int n = Rf_length(t), m = Rf_length(ts);
+    double *p = REAL(params);
+    SEXP draw = PROTECT(Rf_allocVector(REALSXP, m));
+    int rc = gpmi_sample_derivs(ctx(), REAL(t), n, REAL(ts), m, REAL(y), p[0], p[1], p[2], Rf_asReal(jitter), REAL(z),
+                                REAL(draw), NULL);
+    UNPROTECT(1);
+    check(rc);
+    return draw;
+}
+
+/* the loop mclapply(s_list[1:100], sample_derivs_both_states, mc.cores = 2) of pendulum_fit.R:261-268 as ONE call:
+ * params 3 x B, Y n x B, Z m x B -> draws m x B (independent conditionings on the GPU's lanes) */
+SEXP gpmi_R_sample_derivs_batch(SEXP t, SEXP ts, SEXP Y, SEXP params, SEXP jitter, SEXP Z)
+{
+    int n = Rf_length(t), m = Rf_length(ts), B = Rf_ncols(Y);
+    SEXP draws = PROTECT(Rf_allocMatrix(REALSXP, m, B));
+    int *info = (int *)R_alloc(B > 0 ? B : 1, sizeof(int));
+    int rc = gpmi_sample_derivs_batch(ctx(), REAL(t), n, REAL(ts), m, REAL(Y), n, REAL(params), B, Rf_asReal(jitter), REAL(Z),
+                                      m, REAL(draws), m, NULL, 0, info);
+    UNPROTECT(1);
+    check(rc);
+    for (int b = 0; b < B; ++b) check(info[b]);
+    return draws;
+}
+
 /* t(chol(A)) replacement: lower factor, upper zeroed (Stan convention); base-R chol() is t() of this */
 SEXP gpmi_R_potrf(SEXP A)
 {

@@ -213,3 +213,49 @@ def test_reference_second_derivative_posterior_on_the_gpu(ctx, golden):
     mu2 = np.array(g["mu_second"]); cov2 = np.array(g["cov_second"])
     assert np.max(np.abs(mn - mu2)) <= RTOL * np.max(np.abs(mu2))
     assert np.max(np.abs(Kn - cov2)) <= RTOL * np.max(np.abs(cov2))
+
+
+def test_sample_derivs_fused_and_batched(ctx, orc, golden):
+    """sample_derivs (pendulum_fit.R:227-255) as ONE device call -- moments of gp_condition, covariance factored in place,
+    draw = mu + chol(cov) z -- against the oracle's moments (LU solves as in the reference) and numpy's Cholesky, at the
+    reference's own N = 25 data set and at a blocked size; and the batched form (the mclapply loop of :261-268) against
+    single draws bit for bit."""
+    from gp_amd import pendulum
+    g = golden["gp_derivs"]["posterior"]
+    ts = np.array(g["ts"]); y = np.array(g["y"])
+    z = np.random.default_rng(7).standard_normal(ts.size)
+    d = pendulum.sample_derivs([g["l"], g["a"], g["s"]], y, ts, jitter=1e-8, z=z, ctx=ctx)
+    cov = np.array(g["cov_deriv"]) + 1e-8 * np.eye(ts.size)
+    want = np.array(g["mu_deriv"]) + np.linalg.cholesky(cov) @ z      # the reference python's own moments
+    assert np.max(np.abs(d - want)) <= 1e-7 * np.max(np.abs(want))
+    # blocked size, separate prediction times (lorenz.Rmd:80-107)
+    rng = np.random.default_rng(3)
+    n, m = 1800, 1300
+    t = np.sort(rng.uniform(0, n / 10.0, n)); tis = np.sort(rng.uniform(0, n / 10.0, m))
+    yy = np.sin(t) + 0.1 * rng.standard_normal(n)
+    l, a, sy = 0.9, 1.3, 0.1
+    z = rng.standard_normal(m)
+    draw, mu = ctx.sample_derivs(t, tis, yy, l, a, sy, 1e-6, z)
+    K = orc.deriv_cov("QQ", t, t, a, l) + sy * sy * np.eye(n)
+    Ks = orc.deriv_cov("RQ", tis, t, a, l); Kss = orc.deriv_cov("RR", tis, tis, a, l)
+    mu_ref = Ks @ np.linalg.solve(K, yy)
+    cov_ref = Kss - Ks @ np.linalg.solve(K, Ks.T) + 1e-6 * np.eye(m)
+    cov_ref = 0.5 * (cov_ref + cov_ref.T)
+    draw_ref = mu_ref + np.linalg.cholesky(cov_ref) @ z
+    e_mu = np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)); e_d = np.max(np.abs(draw - draw_ref)) / np.max(np.abs(draw_ref))
+    print("sample_derivs n=%d m=%d: mu rel %.2e, draw rel %.2e" % (n, m, e_mu, e_d))
+    assert e_mu <= RTOL and e_d <= 1e-7   # the draw goes through chol(cov) with a 1e-6 jitter: cond ~ 1e6
+    # batch == singles, bit for bit, for B not a multiple of the lane count; a failing draw does not stop the others
+    B = 6
+    P = np.array([[0.9 + 0.02 * b, 1.3, 0.1 + 0.01 * b] for b in range(B)])
+    Y = np.column_stack([yy + 0.01 * b for b in range(B)]); Z = rng.standard_normal((m, B))
+    draws, mus, info = ctx.sample_derivs_batch(t, tis, Y, P, 1e-6, Z)
+    assert np.all(info == 0)
+    for b in (0, 3, 5):
+        db, mb = ctx.sample_derivs(t, tis, Y[:, b], P[b, 0], P[b, 1], P[b, 2], 1e-6, Z[:, b])
+        assert np.array_equal(draws[:, b], db) and np.array_equal(mus[:, b], mb)
+    many = pendulum.sample_derivs_many(list(P), list(Y.T), t, tis=tis, jitter=1e-6, Z=Z, ctx=ctx)
+    assert np.array_equal(many, draws)
+    Pbad = P.copy(); Pbad[2, 2] = 0.0; Pbad[2, 0] = 500.0     # sy = 0, huge length-scale: K is numerically singular
+    _, _, info = ctx.sample_derivs_batch(t, tis, Y, Pbad, 0.0, Z)
+    assert info[2] != 0 and np.all(np.delete(info, 2) != -1)
