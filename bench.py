@@ -291,9 +291,8 @@ def main():
         """Evaluate points lo..hi-1 of this rank.  c3 / c4 go through the grid entry point, which
         overlaps independent points on internal lanes (own workspaces and streams)."""
         if args.workload == "c5":
-            for p in range(lo, hi):
-                ctx.joint_logml_dev(dX.data_ptr(), n, dy.data_ptr(), 1.0, rho[p], sig[p], 1e-6,
-                                    dout[p].data_ptr(), dinfo[p:].data_ptr())
+            ctx.joint_logml_grid_dev(dX.data_ptr(), n, dy.data_ptr(), np.ones(hi - lo), rho[lo:hi], sig[lo:hi], 1e-6,
+                                     dout[lo].data_ptr(), dinfo[lo:].data_ptr())
         else:
             ctx.logml_grid_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), np.ones(hi - lo), rho[lo:hi], sig[lo:hi], 0.0,
                                dout[lo].data_ptr(), dinfo[lo:].data_ptr())
@@ -461,7 +460,7 @@ def main():
                 "c4": "c4: 64-point (rho x sigma) grid at N=%d, D=%d sharded over the ranks; 1 step = the "
                       "whole grid" % (n, D),
                 "c5": "c5: derivative joint [y, y'] covariance, N=%d (matrix order %d), build + fp64 Cholesky "
-                      "+ solve + log-det" % (n, 2 * n)}[args.workload],
+                      "+ solve + log-det, 1 (l, sigma) point per step per GPU" % (n, 2 * n)}[args.workload],
                        "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1,
                        "nb_outer": args.nb_outer or "auto(%d)" % nbo_auto,
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},

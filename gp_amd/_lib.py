@@ -22,7 +22,7 @@ SYMBOLS = (
     "gpmi_se_cov", "gpmi_se_cov_dev", "gpmi_deriv_cov", "gpmi_deriv_cov_dev", "gpmi_deriv_elem",
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
-    "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition", "gpmi_sample_derivs", "gpmi_sample_derivs_batch",
+    "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_joint_logml_grid_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition", "gpmi_sample_derivs", "gpmi_sample_derivs_batch",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
     "gpmi_interp_free", "gpmi_logml_grad",
     "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
@@ -403,6 +403,11 @@ class Context:
     def joint_logml_dev(self, dt_ptr, n, dyy_ptr, alpha, l, sigma, jitter, dout_ptr, dinfo_ptr):
         _chk(self._lib.gpmi_joint_logml_dev(self._h, C.c_void_p(dt_ptr), int(n), C.c_void_p(dyy_ptr), _d(alpha),
                                             _d(l), _d(sigma), _d(jitter), C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
+
+    def joint_logml_grid_dev(self, dt_ptr, n, dyy_ptr, alpha, l, sigma, jitter, dout_ptr, dinfo_ptr):
+        a = _vec(alpha); r = _vec(l); s = _vec(sigma)
+        _chk(self._lib.gpmi_joint_logml_grid_dev(self._h, C.c_void_p(dt_ptr), int(n), C.c_void_p(dyy_ptr), _p(a), _p(r), _p(s),
+                                                 int(a.size), _d(jitter), C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
 
     def se_cov_dev(self, dX_ptr, n, ldx, dY_ptr, m, ldy, D, alpha, ell, diag_add, flags, dK_ptr, ldk):
         ell = _vec(ell)

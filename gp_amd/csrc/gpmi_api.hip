@@ -914,11 +914,9 @@ extern "C" int gpmi_logml_grid(gpmi_ctx *c, const double *X, int n, int ldx, int
     return 0;
 }
 
-extern "C" int gpmi_joint_logml_dev(gpmi_ctx *c, const double *dt, int n, const double *dyy, double alpha,
-                                    double l, double sigma, double jitter, double *d_out3, int *d_info)
+static int joint_logml_core(gpmi_ctx *c, const double *dt, int n, const double *dyy, double alpha, double l, double sigma,
+                            double jitter, double *d_out3, int *d_info)
 {
-    ENTER(c);
-    if (n <= 0 || !dt || !dyy || !d_out3 || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
     int rc;
     const int n2 = 2 * n, M = n2 + 1;
     if ((rc = reserve_ws(c, M, n2))) return rc;
@@ -934,6 +932,44 @@ extern "C" int gpmi_joint_logml_dev(gpmi_ctx *c, const double *dt, int n, const 
     tic(c, 2);
     launch_logml_finalize(c->stream, c->W, ld, n2, n2, c->d_info, d_out3, d_info, c->d_fin);
     tic(c, 3);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gpmi_joint_logml_dev(gpmi_ctx *c, const double *dt, int n, const double *dyy, double alpha,
+                                    double l, double sigma, double jitter, double *d_out3, int *d_info)
+{
+    ENTER(c);
+    if (n <= 0 || !dt || !dyy || !d_out3 || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
+    return joint_logml_core(c, dt, n, dyy, alpha, l, sigma, jitter, d_out3, d_info);
+}
+
+// G independent (alpha, l, sigma) points of the joint [y, y'] model on the same data, on the lanes
+extern "C" int gpmi_joint_logml_grid_dev(gpmi_ctx *c, const double *dt, int n, const double *dyy, const double *alpha,
+                                         const double *l, const double *sigma, int G, double jitter, double *d_out3, int *d_info)
+{
+    ENTER(c);
+    if (G < 0) return gpmi_fail(GPMI_EARG, "negative grid size");
+    if (G == 0) return 0;
+    if (n <= 0 || !dt || !dyy || !alpha || !l || !sigma || !d_out3 || !d_info) return gpmi_fail(GPMI_EARG, "bad argument");
+    for (int g = 0; g < G; ++g)
+        if (!(l[g] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : (G % 5 == 0 ? 5 : 4)));
+    if (lanes > 8) lanes = 8;
+    if (lanes > G) lanes = G;
+    int rc = lanes_prepare(c, lanes);
+    if (rc) return rc;
+    for (int k = 0; k < lanes; ++k)
+        if ((rc = reserve_ws(k ? c->lane[k - 1] : c, 2 * n + 1, 2 * n))) return rc;
+    const int la_saved = c->lookahead;
+    hipStream_t const caller = c->stream;
+    lanes_fork(c, lanes, caller);
+    for (int g = 0; g < G && !rc; ++g) {
+        gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
+        rc = joint_logml_core(lc, dt, n, dyy, alpha[g], l[g], sigma[g], jitter, d_out3 + 3 * (size_t)g, d_info + g);
+    }
+    lanes_join(c, lanes, caller, la_saved);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     return 0;
 }

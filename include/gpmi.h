@@ -176,6 +176,11 @@ GPMI_API int gpmi_joint_logml(gpmi_ctx *ctx, const double *t, int n, const doubl
                      double l, double sigma, double jitter, double *out3);
 GPMI_API int gpmi_joint_logml_dev(gpmi_ctx *ctx, const double *dt, int n, const double *dyy, double alpha,
                          double l, double sigma, double jitter, double *d_out3, int *d_info);
+/* G independent (alpha[g], l[g], sigma[g]) points of the joint model on the same device-resident data, concurrently
+ * on the context's lanes: d_out3[3 g ..], d_info[g] (non-PD points get NaN and the grid continues). */
+GPMI_API int gpmi_joint_logml_grid_dev(gpmi_ctx *ctx, const double *dt, int n, const double *dyy, const double *alpha,
+                                       const double *l, const double *sigma, int G, double jitter, double *d_out3,
+                                       int *d_info);
 
 /* ---- Rcpp export ------------------------------------------------------ */
 

@@ -313,6 +313,25 @@ def test_joint_logml(ctx, orc):
         assert want[3] == 0 and abs(got[0] - want[0]) <= LOGML_RTOL * abs(want[0])
 
 
+def test_joint_logml_grid_on_lanes(ctx, orc):
+    import torch
+    n = 700
+    t = np.linspace(0, 10, n); yy = np.concatenate([np.sin(t), np.cos(t)])
+    dev = torch.device("cuda:0")
+    dt = torch.from_numpy(t).to(dev); dyy = torch.from_numpy(yy).to(dev)
+    G = 6
+    ls = 0.5 * (1 + 0.05 * np.arange(G)); sg = 0.1 * np.ones(G)
+    out = torch.zeros((G, 3), dtype=torch.float64, device=dev); info = torch.zeros(G, dtype=torch.int32, device=dev)
+    ctx.joint_logml_grid_dev(dt.data_ptr(), n, dyy.data_ptr(), np.ones(G), ls, sg, 1e-6, out.data_ptr(), info.data_ptr())
+    ctx.sync()
+    o = out.cpu().numpy()
+    assert np.all(info.cpu().numpy() == 0)
+    for g in (0, 3, 5):
+        assert o[g, 0] == ctx.joint_logml(t, yy, 1.0, ls[g], sg[g], 1e-6)[0]      # lanes == single call, bit for bit
+    want = orc.joint_logml(t, yy, 1.0, ls[4], sg[4], 1e-6)
+    assert abs(o[4, 0] - want[0]) <= LOGML_RTOL * abs(want[0])
+
+
 def test_device_pointer_api_with_torch(ctx, orc):
     import torch
     X, y = orc.synth(500, 3)
