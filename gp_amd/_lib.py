@@ -24,7 +24,7 @@ SYMBOLS = (
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_joint_logml_grid_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition", "gpmi_sample_derivs", "gpmi_sample_derivs_batch",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
-    "gpmi_interp_free", "gpmi_logml_grad",
+    "gpmi_interp_free", "gpmi_logml_grad", "gpmi_logml_grad_grid",
     "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
     "gpmi_last_timing", "gpmi_kernel_timing",
 )
@@ -295,6 +295,18 @@ class Context:
         _chk(self._lib.gpmi_logml_grad(self._h, _p(X), n, max(n, 1), D, _p(y), _d(alpha), _p(ell), ell.size, _d(sigma),
                                        _d(jitter), _p(out), _p(g)))
         return out, g
+
+    def logml_grad_grid(self, X, y, alpha, rho, sigma, jitter=0.0):
+        """(out (G, 3), grad (G, 3), info (G,)): value and (d/dalpha, d/drho, d/dsigma) at G points, on the lanes."""
+        X = _mat(X); y = _vec(y)
+        n, D = X.shape
+        alpha, rho, sigma = np.broadcast_arrays(np.asarray(alpha, float), np.asarray(rho, float), np.asarray(sigma, float))
+        a = _vec(alpha); r = _vec(rho); s = _vec(sigma)
+        G = a.size
+        out = np.empty((G, 3)); g = np.empty((G, 3)); info = np.zeros(G, dtype=np.int32)
+        _chk(self._lib.gpmi_logml_grad_grid(self._h, _p(X), n, max(n, 1), D, _p(y), _p(a), _p(r), _p(s), G, _d(jitter),
+                                            _p(out), _p(g), _p(info)))
+        return out, g, info
 
     # ---- Cholesky-factor interpolation over the length-scale ------------------
     def interp_build(self, x, lp):

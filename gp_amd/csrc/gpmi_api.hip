@@ -1403,6 +1403,72 @@ __global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ 
 }
 }  // namespace
 
+// every buffer logml_grad_core(c, ., n, ...) uses, at its final size
+static int logml_grad_reserve(gpmi_ctx *c, int n)
+{
+    int rc;
+    if ((rc = reserve_ws(c, n + 1, n))) return rc;
+    const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
+    const int nchunk = (n + UMV_COLS - 1) / UMV_COLS;
+    double *b;
+    if ((rc = stage_buf(c, 2, ldu * (size_t)(n + 1) * sizeof(double), &b))) return rc;
+    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS + ntiles * GRAD_NS + (size_t)nchunk * n) * sizeof(double), &b))) return rc;
+    return scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &b);
+}
+
+// Device part of one value + gradient evaluation, enqueued on c->stream without synchronisation:
+// d_res[0..2] = (logml, sum log L_ii, z'z), d_res[3 .. 3 + GRAD_NS) = the contraction sums, *d_info = status
+constexpr int GRAD_RES = 3 + GRAD_NS;
+static int logml_grad_core(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
+                           double *d_res, int *d_info)
+{
+    int rc;
+    if ((rc = logml_grad_reserve(c, n))) return rc;
+    const int M = n + 1;
+    const size_t ld = (size_t)c->ld;
+    const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
+    const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
+    const int nchunk = (n + UMV_COLS - 1) / UMV_COLS;
+    double *U = c->stage[2], *vec = c->stage[3], *Fall = c->scratch;
+    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS, *mvpart = part + ntiles * GRAD_NS;
+    hipStream_t s = c->stream;
+    // factorisation with the augmented row, all panel factors kept
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    launch_se_cov(c, s, dX, n, ldx, nullptr, n, ldx, p, diag_add, 1, c->W, ld);
+    launch_set_row(s, c->W, ld, n, dy, n, n);
+    if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, Fall))) return rc;
+    launch_logml_finalize(s, c->W, ld, n, n, c->d_info, d_res, d_info, c->d_fin);
+    launch_get_row(s, c->W, ld, n, 0, n, 1.0, zv);
+    // U = L^-T, a = U z = K^-1 y
+    hipLaunchKernelGGL(k_set_identity, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, ldu, n);
+    if ((rc = launch_trsm_right(c, c->W, ld, n, U, ldu, n, Fall, 1))) return rc;
+    hipLaunchKernelGGL(k_upper_mv_part, dim3((n + UMV_ROWS - 1) / UMV_ROWS, nchunk), UMV_ROWS, 0, s, U, ldu, n, zv, mvpart);
+    hipLaunchKernelGGL(k_upper_mv_sum, dim3((n + 255) / 256), 256, 0, s, mvpart, n, nchunk, av);
+    // W(lower) = -U U^T = -K^-1
+    HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
+    launch_syrk_uut(c, s, U, ldu, c->W, ld, n);
+    hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, ldx, p, av, c->W, ld, part);
+    hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, d_res + 3);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// host part: (d/dalpha, d/dell..., d/dsigma) from the contraction sums
+static void logml_grad_finish(const double *hs, int D, double alpha, const double *ell, int n_ell, double sigma, double *grad)
+{
+    grad[0] = 2.0 * hs[0] / alpha;
+    if (n_ell == 1) {
+        double t = 0.0;
+        for (int d = 0; d < D; ++d) t += hs[1 + d];
+        grad[1] = t / (ell[0] * ell[0] * ell[0]);
+    } else {
+        for (int d = 0; d < D; ++d) grad[1 + d] = hs[1 + d] / (ell[d] * ell[d] * ell[d]);
+    }
+    grad[1 + n_ell] = 2.0 * sigma * hs[1 + GPMI_MAXD];
+}
+
 extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
                                double alpha, const double *ell, int n_ell, double sigma, double jitter,
                                double *out3, double *grad)
@@ -1413,58 +1479,80 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     SeParams p;
     int rc;
     if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
-    double *dX, *dy;
+    double *dX, *dy, *dres;
     if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
-    const int M = n + 1;
-    if ((rc = reserve_ws(c, M, n))) return rc;
-    const size_t ld = (size_t)c->ld;
-    const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
-    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
-    const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
-    double *U, *vec, *Fall;
-    if ((rc = stage_buf(c, 2, ldu * (size_t)(n + 1) * sizeof(double), &U))) return rc;
-    const int nchunk = (n + UMV_COLS - 1) / UMV_COLS;
-    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS + ntiles * GRAD_NS + (size_t)nchunk * n) * sizeof(double), &vec))) return rc;
-    if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
-    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS, *mvpart = part + ntiles * GRAD_NS;
-    hipStream_t s = c->stream;
-    // factorisation with the augmented row, all panel factors kept
-    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
-    launch_se_cov(c, s, dX, n, n, nullptr, n, n, p, sigma * sigma + jitter, 1, c->W, ld);
-    launch_set_row(s, c->W, ld, n, dy, n, n);
-    if ((rc = launch_potrf_partial(c, c->W, ld, M, n, n, c->d_info, Fall))) return rc;
-    launch_logml_finalize(s, c->W, ld, n, n, c->d_info, c->d_out, c->d_info + 1, c->d_fin);
-    launch_get_row(s, c->W, ld, n, 0, n, 1.0, zv);
-    // U = L^-T, a = U z = K^-1 y
-    hipLaunchKernelGGL(k_set_identity, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, ldu, n);
-    if ((rc = launch_trsm_right(c, c->W, ld, n, U, ldu, n, Fall, 1))) return rc;
-    hipLaunchKernelGGL(k_upper_mv_part, dim3((n + UMV_ROWS - 1) / UMV_ROWS, nchunk), UMV_ROWS, 0, s, U, ldu, n, zv, mvpart);
-    hipLaunchKernelGGL(k_upper_mv_sum, dim3((n + 255) / 256), 256, 0, s, mvpart, n, nchunk, av);
-    // W(lower) = -U U^T = -K^-1
-    HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
-    launch_syrk_uut(c, s, U, ldu, c->W, ld, n);
-    hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, n, p, av, c->W, ld, part);
-    hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, sums);
-    HIPCHK(hipGetLastError());
-    double hs[GRAD_NS];
+    if ((rc = logml_grad_reserve(c, n))) return rc;
+    dres = c->d_fin + 4096;  // second half of the finalize scratch (64 KiB): GRAD_RES doubles
+    if ((rc = logml_grad_core(c, dX, n, n, dy, p, sigma * sigma + jitter, dres, c->d_info + 1))) return rc;
+    double hr[GRAD_RES];
     int info = 0;
-    HIPCHK(hipMemcpyAsync(out3, c->d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    hipStream_t s = c->stream;
+    HIPCHK(hipMemcpyAsync(hr, dres, sizeof(hr), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&info, c->d_info + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hs, sums, sizeof(hs), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    for (int k = 0; k < 3; ++k) out3[k] = hr[k];
     if (info) {
         for (int k = 0; k < 2 + n_ell; ++k) grad[k] = NAN;
         return info;
     }
-    grad[0] = 2.0 * hs[0] / alpha;
-    if (n_ell == 1) {
-        double t = 0.0;
-        for (int d = 0; d < D; ++d) t += hs[1 + d];
-        grad[1] = t / (ell[0] * ell[0] * ell[0]);
-    } else {
-        for (int d = 0; d < D; ++d) grad[1 + d] = hs[1 + d] / (ell[d] * ell[d] * ell[d]);
+    logml_grad_finish(hr + 3, D, alpha, ell, n_ell, sigma, grad);
+    return 0;
+}
+
+// G independent (alpha[g], rho[g], sigma[g]) points: value AND gradient of each, concurrently on the lanes -- what
+// rstan's default four chains ask for per leapfrog step (pendulum_fit.R:140: chains = 4, cores = 4), one
+// evaluation + reverse sweep of models/fit_hyperparameters.stan:18-32 each.  out3: 3 G, grad: 3 G
+// (d/dalpha, d/drho, d/dsigma per point), info: G (non-PD points: NaN and the grid continues).
+extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y, const double *alpha,
+                                    const double *rho, const double *sigma, int G, double jitter, double *out3, double *grad,
+                                    int *info)
+{
+    ENTER(c);
+    if (G < 0) return gpmi_fail(GPMI_EARG, "negative grid size");
+    if (G == 0) return 0;
+    if (n <= 0 || !X || !y || !alpha || !rho || !sigma || !out3 || !grad || !info || ldx < n || D < 1)
+        return gpmi_fail(GPMI_EARG, "bad argument");
+    if (D > GPMI_MAXD) return gpmi_fail(GPMI_EARG, "gradient supports D <= %d", GPMI_MAXD);
+    int rc;
+    std::vector<SeParams> ps(G);
+    for (int g = 0; g < G; ++g)
+        if ((rc = fill_params(&ps[g], D, alpha[g], &rho[g], 1))) return rc;
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
+    if (lanes > 8) lanes = 8;
+    if (lanes > G) lanes = G;
+    if ((rc = lanes_prepare(c, lanes))) return rc;
+    for (int k = 0; k < lanes; ++k)
+        if ((rc = logml_grad_reserve(k ? c->lane[k - 1] : c, n))) return rc;
+    double *dX, *dy, *dres;
+    if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
+    // the root context's scratch also holds its packed panel factors (logml_grad_reserve): the results live behind them
+    const int npan = (n + GPMI_NB - 1) / GPMI_NB;
+    if ((rc = scratch_buf(c, ((size_t)npan * GPMI_FPACK + (size_t)G * (GRAD_RES + 1) + 8) * sizeof(double), &dres))) return rc;
+    dres += (size_t)npan * GPMI_FPACK;
+    int *dinfo = (int *)(dres + (size_t)G * GRAD_RES);
+    const int la_saved = c->lookahead;
+    hipStream_t const caller = c->stream;
+    lanes_fork(c, lanes, caller);
+    for (int g = 0; g < G && !rc; ++g) {
+        gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
+        rc = logml_grad_core(lc, dX, n, n, dy, ps[g], sigma[g] * sigma[g] + jitter, dres + (size_t)g * GRAD_RES, dinfo + g);
     }
-    grad[1 + n_ell] = 2.0 * sigma * hs[1 + GPMI_MAXD];
+    lanes_join(c, lanes, caller, la_saved);
+    if (rc) return rc;
+    std::vector<double> hr((size_t)G * GRAD_RES);
+    HIPCHK(hipMemcpyAsync(hr.data(), dres, hr.size() * sizeof(double), hipMemcpyDeviceToHost, caller));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, caller));
+    HIPCHK(hipStreamSynchronize(caller));
+    HIPCHK(hipGetLastError());
+    for (int g = 0; g < G; ++g) {
+        const double *r = hr.data() + (size_t)g * GRAD_RES;
+        for (int k = 0; k < 3; ++k) out3[3 * g + k] = r[k];
+        if (info[g]) {
+            for (int k = 0; k < 3; ++k) grad[3 * g + k] = NAN;
+        } else {
+            logml_grad_finish(r + 3, D, alpha[g], &rho[g], 1, sigma[g], grad + 3 * g);
+        }
+    }
     return 0;
 }
 

@@ -48,6 +48,19 @@ def fit_hyperparameters_log_prob_grad(t, y, rho, alpha, sigma, ctx=None):
     return lp, np.array([g[1] + 4.0 / rho - 4.0, g[0] + 1.0 / alpha - alpha, g[2] + 1.0 / sigma - sigma])
 
 
+def fit_hyperparameters_log_prob_grad_chains(t, y, rho, alpha, sigma, ctx=None):
+    """The same for several chains at once -- rstan runs `chains = 4` (pendulum_fit.R:140), each asking for one
+    value + gradient per leapfrog step: (lp (C,), grad (C, 3) in (rho, alpha, sigma) order), evaluated
+    concurrently on the GPU's lanes; rejected (non-PD) proposals get -inf / NaN."""
+    rho = np.atleast_1d(np.asarray(rho, float)); alpha = np.atleast_1d(np.asarray(alpha, float))
+    sigma = np.atleast_1d(np.asarray(sigma, float))
+    out, g, info = (ctx or default_context()).logml_grad_grid(t, y, alpha, rho, sigma, 0.0)
+    lp = np.array([stan_lp(o[1], o[2], a, r, s) if i == 0 else -math.inf for o, a, r, s, i in zip(out, alpha, rho, sigma, info)])
+    grad = np.column_stack([g[:, 1] + 4.0 / rho - 4.0, g[:, 0] + 1.0 / alpha - alpha, g[:, 2] + 1.0 / sigma - sigma])
+    grad[info != 0] = math.nan
+    return lp, grad
+
+
 def gp_log_marginal_grid(X, y, alpha, rho_vec, sigma_vec, jitter=0.0, lp=False, ctx=None):
     """|rho| x |sigma| matrix of log marginal likelihoods (lp=True: Stan lp__ instead);
     non-PD points are NaN (-inf for lp) and the grid continues."""

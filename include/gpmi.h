@@ -158,6 +158,13 @@ GPMI_API int gpmi_logml_grad(gpmi_ctx *ctx, const double *X, int n, int ldx, int
                     double alpha, const double *ell, int n_ell, double sigma, double jitter,
                     double *out3, double *grad);
 
+/* Value AND gradient at G independent points (alpha[g], rho[g], sigma[g]), concurrently on the context's lanes: what
+ * rstan's default four chains (pendulum_fit.R:140: chains = 4, cores = 4) ask for per leapfrog step.  out3: 3 G;
+ * grad: 3 G, (d/dalpha, d/drho, d/dsigma) per point; info: G (non-PD: NaN, the grid continues).  D <= 8. */
+GPMI_API int gpmi_logml_grad_grid(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+                                  const double *alpha, const double *rho, const double *sigma, int G, double jitter,
+                                  double *out3, double *grad, int *info);
+
 /* G independent hyper-parameter points (alpha[g], rho[g], sigma[g]) on the same
  * data: out3[3*g..], info[g].  Non-PD points get NaN and info[g] = k and the
  * grid continues.  Replaces the stan()-fit + arg-max of R/tests.R:13-27 when a

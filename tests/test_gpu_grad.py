@@ -75,3 +75,23 @@ def test_grad_fullsize_n8192_property(ctx, orc):
     f = lambda q: ctx.logml(X, y, a + q * d[0], [r + q * d[1]], s + q * d[2])[0]
     fd = (f(h) - f(-h)) / (2 * h)
     assert g @ d == pytest.approx(fd, rel=5e-6)
+
+
+def test_grad_grid_on_lanes_equals_single_calls(ctx, orc):
+    """gpmi_logml_grad_grid (value + gradient of several points at once: what rstan's four chains ask for per
+    leapfrog step) equals gpmi_logml_grad point by point, bit for bit, for G not a multiple of the lane count, with
+    a non-PD point in the middle; and the Stan-lp wrapper adds the prior / Jacobian terms."""
+    from gp_amd import stan_models as sm
+    X, y = orc.synth(900, 3)
+    a = np.array([1.0, 1.1, 0.9, 1.0, 1.2]); r = np.array([0.3, 0.35, 0.25, 50.0, 0.3]); s = np.array([0.1, 0.12, 0.2, 1e-9, 0.15])
+    out, g, info = ctx.logml_grad_grid(X, y, a, r, s)
+    assert info[3] > 0 and np.all(np.isnan(g[3])) and np.all(np.delete(info, 3) == 0)
+    for k in (0, 1, 2, 4):
+        o1, g1 = ctx.logml_grad(X, y, a[k], [r[k]], s[k])
+        assert np.array_equal(out[k], o1) and np.array_equal(g[k], g1)
+    wo, wg, winfo = orc.logml_grad(X, y, a[1], r[1], s[1])
+    np.testing.assert_allclose(g[1], wg, rtol=1e-8, atol=1e-8 * np.abs(wg).max())
+    lp, grad = sm.fit_hyperparameters_log_prob_grad_chains(X, y, r, a, s, ctx=ctx)
+    assert lp[3] == -math.inf and np.all(np.isnan(grad[3]))
+    lp1, grad1 = sm.fit_hyperparameters_log_prob_grad(X, y, r[2], a[2], s[2], ctx=ctx)
+    assert lp[2] == lp1 and np.array_equal(grad[2], grad1)
