@@ -63,6 +63,7 @@ rbf_cov_chol <- function(x1, l_) .Call("gpmi_R_rbf_cov_chol", as.double(x1), l_)
 # covariance.cpp:49-96 and models/cubic_interpolated_gp.hpp:38-73 (test_interpolate.R:9-19 builds the table)
 approx_L <- function(l, lp, Ls, dLdls) .Call("gpmi_R_approx_L", l, as.double(lp), Ls, dLdls)
 approx_Lz <- function(l, lp, Ls, dLdls, z) .Call("gpmi_R_approx_Lz", l, as.double(lp), Ls, dLdls, as.double(z))
+approx_Lz_grad <- function(l, lp, Ls, dLdls, z) .Call("gpmi_R_approx_Lz_grad", l, as.double(lp), Ls, dLdls, as.double(z))
 gp_interp_build <- function(x, lp) invisible(.Call("gpmi_R_interp_build", as.double(x), as.double(lp)))
 gp_interp_Lz <- function(l, z) .Call("gpmi_R_approx_Lz", l, numeric(0), NULL, NULL, as.double(z))
 
@@ -73,6 +74,10 @@ gp_log_marginal <- function(X, y, alpha, rho, sigma, jitter = 0)
 # value and gradient w.r.t. (alpha, rho, sigma): feeds optim(..., method = "L-BFGS-B") in place of a Stan fit
 gp_log_marginal_grad <- function(X, y, alpha, rho, sigma, jitter = 0)
   .Call("gpmi_R_logml_grad", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)
+
+# the same for several chains' (alpha, rho, sigma) at once (rstan: chains = 4), concurrently on the GPU
+gp_log_marginal_grad_chains <- function(X, y, alpha, rho, sigma, jitter = 0)
+  .Call("gpmi_R_logml_grad_grid", as.matrix(X), as.double(y), as.double(alpha), as.double(rho), as.double(sigma), jitter)
 
 gp_log_marginal_grid <- function(X, y, alpha, rho_vec, sigma_vec, jitter = 0) {
   g <- expand.grid(rho = rho_vec, sigma = sigma_vec)

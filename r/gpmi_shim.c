@@ -147,6 +147,23 @@ SEXP gpmi_R_approx_Lz(SEXP l, SEXP lp, SEXP Ls, SEXP dLdls, SEXP z)
     return f;
 }
 
+/* list(f = approx_L(l) z, dfdl = (dv/dl) z): value and the reverse-mode partial of the Stan external function
+ * (`var` overload of build_output, models/cubic_interpolated_gp.hpp:6-32, dvdl :67) */
+SEXP gpmi_R_approx_Lz_grad(SEXP l, SEXP lp, SEXP Ls, SEXP dLdls, SEXP z)
+{
+    int n = Rf_length(z);
+    if (!Rf_isNull(Ls)) check(load_pair(Rf_asReal(l), lp, Ls, dLdls, &n));
+    SEXP f = PROTECT(Rf_allocVector(REALSXP, n)), g = PROTECT(Rf_allocVector(REALSXP, n));
+    int rc = gpmi_approx_Lz_grad(ctx(), Rf_asReal(l), REAL(z), REAL(f), REAL(g));
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2)), names = PROTECT(Rf_allocVector(STRSXP, 2));
+    SET_VECTOR_ELT(out, 0, f); SET_VECTOR_ELT(out, 1, g);
+    SET_STRING_ELT(names, 0, Rf_mkChar("f")); SET_STRING_ELT(names, 1, Rf_mkChar("dfdl"));
+    Rf_setAttrib(out, R_NamesSymbol, names);
+    UNPROTECT(4);
+    check(rc);
+    return out;
+}
+
 /* c(logml, sum log L_ii, z'z): one evaluation of models/fit_hyperparameters.stan:18-32 */
 SEXP gpmi_R_logml(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)
 {
@@ -171,6 +188,20 @@ SEXP gpmi_R_logml_grad(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP ji
     SET_VECTOR_ELT(out, 0, val); SET_VECTOR_ELT(out, 1, g);
     SET_STRING_ELT(names, 0, Rf_mkChar("value")); SET_STRING_ELT(names, 1, Rf_mkChar("grad"));
     Rf_setAttrib(out, R_NamesSymbol, names);
+    UNPROTECT(4);
+    check(rc);
+    return out;
+}
+
+/* value + gradient at G points (one per chain): list(value = 3 x G, grad = 3 x G (d/dalpha, d/drho, d/dsigma), info) */
+SEXP gpmi_R_logml_grad_grid(SEXP X, SEXP y, SEXP alpha, SEXP rho, SEXP sigma, SEXP jitter)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X), G = Rf_length(rho);
+    SEXP val = PROTECT(Rf_allocMatrix(REALSXP, 3, G)), g = PROTECT(Rf_allocMatrix(REALSXP, 3, G)), info = PROTECT(Rf_allocVector(INTSXP, G));
+    int rc = gpmi_logml_grad_grid(ctx(), REAL(X), n, n, D, REAL(y), REAL(alpha), REAL(rho), REAL(sigma), G, Rf_asReal(jitter),
+                                  REAL(val), REAL(g), INTEGER(info));
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 3));
+    SET_VECTOR_ELT(out, 0, val); SET_VECTOR_ELT(out, 1, g); SET_VECTOR_ELT(out, 2, info);
     UNPROTECT(4);
     check(rc);
     return out;
