@@ -189,7 +189,10 @@ __device__ __forceinline__ double ld_blk(const double *p)
 constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 2 * 16 * 17;  // doubles of workgroup memory the body needs (52 KB)
 // COH: the block was written by other workgroups of the same launch with agent-scope stores; read it
 // with agent-scope loads (they do not trust this XCD's L2) instead of invalidating caches with a fence
-template <bool COH = false>
+// FULL: the block has all 128 rows and columns (every panel but a ragged last one): the tiles below the
+// diagonal are loaded and stored unconditionally -- the guarded form costs a compare, an exec-mask
+// save / restore and a branch per ELEMENT (60 per lane), ~3 us per block
+template <bool COH = false, bool FULL = false>
 __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double *__restrict__ A, size_t lda, int nb_act,
                                                  double *__restrict__ Fpack, int *info, int col0)
 {
@@ -230,7 +233,8 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
                 const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
                 const int rr = row > col ? row : col, cc = row > col ? col : row;                      \
-                T[jb][i] = (rr < nb_act) ? ld_blk<COH>(A + (size_t)rr + (size_t)cc * lda) : (row == col ? 1.0 : 0.0); \
+                if (FULL) T[jb][i] = ld_blk<COH>(A + (size_t)rr + (size_t)cc * lda);                   \
+                else T[jb][i] = (rr < nb_act) ? ld_blk<COH>(A + (size_t)rr + (size_t)cc * lda) : (row == col ? 1.0 : 0.0); \
             }                                                                                          \
         }                                                                                              \
     }
@@ -307,7 +311,8 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
         if (jb <= (br)) {                                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
                 const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
-                if (row < nb_act && col <= row) A[(size_t)row + (size_t)col * lda] = T[jb][i];         \
+                if (FULL ? (jb < (br) || col <= row) : (row < nb_act && col <= row))                   \
+                    A[(size_t)row + (size_t)col * lda] = T[jb][i];                                     \
             }                                                                                          \
             if (jb < (br)) {                                                                           \
                 _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                       \
@@ -335,7 +340,8 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, 
                                                      double *__restrict__ Fpack, int *info, int col0)
 {
     __shared__ double sm[DIAG4_LDS];
-    potrf_diag4_body(sm, A, lda, nb_act, Fpack, info, col0);
+    if (nb_act == GPMI_NB) potrf_diag4_body<false, true>(sm, A, lda, nb_act, Fpack, info, col0);
+    else potrf_diag4_body<false, false>(sm, A, lda, nb_act, Fpack, info, col0);
 }
 
 // ---------------------------------------------------------------------------
@@ -735,6 +741,7 @@ __device__ __forceinline__ void stagger_start(double (&smem)[2][2][GK][GP], int 
 // own tile is stored, while the other workgroups of the launch are still updating.  The
 // diagonal-block latency chain (27 us per panel) then runs inside the update instead of after
 // it, needs no launch and no free CU of its own, and the panel solve follows directly.
+constexpr int SUBWG = 9;  // workgroups (x 4 waves = 36 sub-tiles of 16 x 16) of the sub-tiled diagonal tile of a fused launch
 struct FuseDiag {
     double *Fp;   // packed-factor slot of that panel; nullptr: no fusion
     int *info;
@@ -743,81 +750,62 @@ struct FuseDiag {
     int *ctr;     // zeroed device counter for the sub-tiled variant (order bit 9)
 };
 
-// 64 x 64 sub-tile of C -= A B^T at (sm0, sn0), one workgroup, fragments straight from global
-// memory (L2-resident panel), no LDS, no barriers: wave w owns the 32 x 32 block (w & 1, w >> 1)
-// as 2 x 2 MFMA tiles, operands of 8 k-groups in flight behind the 8 being multiplied.
-// Requires K % 32 == 0.  mv / nv: valid rows of A / B counted from the tile origin (operand rows
-// past them are clamped, outputs past them dropped).
+// 16 x 16 sub-tile of C -= A B^T at (m0, n0), ONE wave, fragments straight from global memory with EVERY
+// load of a 128-wide K range in flight at once (two sets of 16 k-groups = 64 loads per lane): the operands
+// were written by the previous kernel on other CUs / XCDs and come from HBM or the Infinity Cache, so
+// the cost of a sub-tile is memory round trips, not matrix work -- the 64 x 64 form above (8 k-groups in
+// flight behind 8 being multiplied) took 3 dependent round trips at K = 128 (~11 us), this one takes one.
+// Two accumulators halve the dependent MFMA chain.  Requires K % 64 == 0; the tile lies wholly inside C.
 template <bool COH = false>
-__device__ __forceinline__ void gemm_sub64(const double *__restrict__ A, size_t lda, const double *__restrict__ B,
-                                           size_t ldb, double *__restrict__ C, size_t ldc, int K, int sm0, int sn0,
-                                           int mv, int nv)
+__device__ __forceinline__ void gemm_sub16(const double *__restrict__ A, size_t lda, const double *__restrict__ B, size_t ldb,
+                                           double *__restrict__ C, size_t ldc, int K, int m0, int n0)
 {
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int mb = sm0 + (w & 1) * 32, nb = sn0 + (w >> 1) * 32;
-    if (mb >= mv || nb >= nv) return;  // wave-uniform
-    int ra[2], rb[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        ra[t] = mb + t * 16 + lr;
-        ra[t] = ra[t] < mv ? ra[t] : mv - 1;
-        rb[t] = nb + t * 16 + lr;
-        rb[t] = rb[t] < nv ? rb[t] : nv - 1;
-    }
-    const double *pa = A + (size_t)lq * lda;  // bf[tm] = pa[ra[tm] + k * lda]
-    const double *pb = B + (size_t)lq * ldb;  // af[tn] = pb[rb[tn] + k * ldb]
-    d4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-    double fa[2][8][2], fb[2][8][2];
+    const double *pa = A + (size_t)(m0 + lr) + (size_t)lq * lda;  // bf = pa[k * lda]
+    const double *pb = B + (size_t)(n0 + lr) + (size_t)lq * ldb;  // af = pb[k * ldb]
+    d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+    double fa[2][16], fb[2][16];
+    // ONE running offset per operand, opaque to the optimiser: with per-load offsets it materialises all 64
+    // addresses (128 registers) next to the 128 registers of loaded operands and spills the operands (the
+    // offset, not the pointer, is made opaque: the loads stay global_load, not flat_load)
+    const size_t sa = 4 * lda, sb = 4 * ldb;
     auto load = [&](int set, int k0) {
+        size_t oa = (size_t)k0 * lda, ob = (size_t)k0 * ldb;
 #pragma unroll
-        for (int g = 0; g < 8; ++g)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                fa[set][g][t] = pb[rb[t] + (size_t)(k0 + 4 * g) * ldb];
-                fb[set][g][t] = pa[ra[t] + (size_t)(k0 + 4 * g) * lda];
-            }
+        for (int g = 0; g < 16; ++g) {
+            fa[set][g] = pb[ob];
+            fb[set][g] = pa[oa];
+            oa += sa;
+            ob += sb;
+            asm volatile("" : "+v"(oa), "+v"(ob));
+        }
     };
     auto mul = [&](int set) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) acc[tn][tm] = mfma(fa[set][g][tn], fb[set][g][tm], acc[tn][tm]);
+        for (int g = 0; g < 16; g += 2) {
+            acc0 = mfma(fa[set][g], fb[set][g], acc0);
+            acc1 = mfma(fa[set][g + 1], fb[set][g + 1], acc1);
+        }
     };
     load(0, 0);
+    if (K > 64) load(1, 64);
 #pragma unroll 1
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        if (k0 + 32 < K) load(1, k0 + 32);
+    for (int k0 = 0; k0 < K; k0 += 128) {
         mul(0);
-        if (k0 + 32 < K) {
-            if (k0 + 64 < K) load(0, k0 + 64);
+        if (k0 + 128 < K) load(0, k0 + 128);
+        if (k0 + 64 < K) {
             mul(1);
+            if (k0 + 192 < K) load(1, k0 + 192);
         }
     }
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = mb + tm * 16 + lr, n = nb + tn * 16 + lq + 4 * i;
-                if (m < mv && n < nv) {
-                    double *q = C + (size_t)m + (size_t)n * ldc;
-                    const double v = *q - acc[tn][tm][i];
-                    // COH: agent-scope store (written through this XCD's L2): another CU, possibly on
-                    // another XCD, reads the sub-tile in the same launch, and a release FENCE would
-                    // write back the whole L2 instead of these 32 KiB
-                    if constexpr (COH) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else *q = v;
-                }
-            }
+    for (int i = 0; i < 4; ++i) {
+        double *q = C + (size_t)(m0 + lr) + (size_t)(n0 + lq + 4 * i) * ldc;
+        const double v = *q - (acc0[i] + acc1[i]);
+        if constexpr (COH) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *q = v;
+    }
 }
 
 // 64 x 64 tile of C -= A B^T, LDS-staged: the quadrant kernel of the SYRK tail split.  Four waves
@@ -984,15 +972,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         }
     } else if (MODE == 0 && (order & 0x200)) {
         // Sub-tiled fused launch (1-D grid): the diagonal tile (0, 0) sits on the critical path of
-        // the panel chain and one workgroup needs K * 256 cycles for it, so its lower triangle is
-        // cut into three 64 x 64 sub-tiles on three CUs (blocks 0..2, dispatched first); block 0
-        // waits for the other two and factors the block.  Blocks >= 3 are the tiles 1, 2, ...
+        // the panel chain and one workgroup needs K * 256 cycles for it, plus the memory latency of
+        // operands the previous kernel has just written elsewhere.  Its lower triangle is cut into 36
+        // 16 x 16 sub-tiles, one per wave of the first SUBWG = 9 workgroups (dispatched first, so
+        // all are resident and the wait below cannot deadlock), each with all its operand loads in
+        // flight at once; block 0 waits for the other eight and factors the block.  Blocks >= SUBWG
+        // are the tiles 1, 2, ...
         const int b = blockIdx.x;
-        if (b < 3) {
+        if (b < SUBWG) {
 #ifdef GPMI_PROBES
             const unsigned long long fz0 = __builtin_amdgcn_s_memtime();
 #endif
-            gemm_sub64<true>(A, lda, B, ldb, C, ldc, K, b ? 64 : 0, b == 2 ? 64 : 0, GT, GT);
+            {
+                const int t = b * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // sub-tile index, row-major lower triangle
+                int tm = 0;
+                while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+                const int tn = t - tm * (tm + 1) / 2;
+                gemm_sub16<true>(A, lda, B, ldb, C, ldc, K, tm * 16, tn * 16);
+            }
             // the agent-scope stores above are complete (acknowledged by the memory side) once
             // vmcnt drains; no cache-wide fence is needed around this hand-over
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1005,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
             const unsigned long long fz1 = __builtin_amdgcn_s_memtime();
 #endif
             if (threadIdx.x == 0) {
-                while (__hip_atomic_load(fd.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2)
+                while (__hip_atomic_load(fd.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < SUBWG - 1)
                     __builtin_amdgcn_s_sleep(4);
                 __hip_atomic_store(fd.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
             }
@@ -1013,7 +1010,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
 #ifdef GPMI_PROBES
             const unsigned long long fz2 = __builtin_amdgcn_s_memtime();
 #endif
-            potrf_diag4_body<true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+            if (fd.nb == GPMI_NB) potrf_diag4_body<true, true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+            else potrf_diag4_body<true, false>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
 #ifdef GPMI_PROBES
             if (threadIdx.x == 0) {
                 atomicAdd(&g_fz[0], fz1 - fz0);
@@ -1026,8 +1024,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
             return;
         }
         const int gx = (M + GT - 1) / GT;
-        ti = (b - 2) % gx;
-        tj = (b - 2) / gx;
+        ti = (b - (SUBWG - 1)) % gx;
+        tj = (b - (SUBWG - 1)) / gx;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1055,7 +1053,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         __threadfence();
         __syncthreads();
         __threadfence();
-        potrf_diag4_body(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+        if (fd.nb == GPMI_NB) potrf_diag4_body<false, true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+        else potrf_diag4_body<false, false>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
     }
 }
 
@@ -1710,8 +1709,8 @@ static bool launch_gemm_nt_fused(const gpmi_ctx *c, hipStream_t s, const double 
 {
     if (!(c->tune.fuse_diag & 1) || (c->tune.gemm_variant != 3 && c->tune.gemm_variant != 0) || M <= 0 || N <= 0 || K <= 0) return false;
     dim3 grid((M + GT - 1) / GT, (N + GT - 1) / GT);
-    if ((c->tune.fuse_diag & 4) && fd.ctr && M >= GT && N >= GT && K % 32 == 0) {  // tile (0, 0) interior: sub-tiled
-        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(grid.x * grid.y + 2), 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0x200, 0, fd, KSplit{});
+    if ((c->tune.fuse_diag & 4) && fd.ctr && M >= GT && N >= GT && K % 64 == 0) {  // tile (0, 0) interior: sub-tiled
+        hipLaunchKernelGGL(k_gemm_nt<0>, dim3(grid.x * grid.y + SUBWG - 1), 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0x200, 0, fd, KSplit{});
         return true;
     }
     hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, fd, KSplit{});
