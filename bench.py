@@ -490,7 +490,7 @@ def main():
                 "flops_per_launch_avg": syrk_flops / max(syrk_n, 1),
             },
             "roofline_panel": {
-                "kernel": "panel phase of one outer block: k_potrf_diag + k_trsm_panel + k_gemm_nt<0> (in-block "
+                "kernel": "panel phase of one outer block: k_potrf_diag4 + k_trsm_panel + k_gemm_nt<0> (in-block "
                           "products with the fused diagonal blocks); latency chain, 128 sequential pivot blocks",
                 "bound": "mfma",
                 "achieved": pach,

@@ -12,8 +12,9 @@
 // rows (128 contiguous bytes) of 4 columns.
 //
 // Kernels
-//   k_potrf_diag  one workgroup: factor a <=128x128 diagonal block, emit its
+//   k_potrf_diag4 one workgroup: factor a <=128x128 diagonal block, emit its
 //                 factors packed in fragment order (Fpack) for the panel solve
+//                 (k_potrf_diag: the 5-wave form of round 1, kept as an option)
 //   k_trsm_panel  rows below the block: X = A21 L11^-T by blocked substitution,
 //                 each wave owns 16 rows and chains MFMAs through registers
 //   k_gemm_nt     C -= A B^T / C = A B^T, 128x128 tiles, LDS-staged with
