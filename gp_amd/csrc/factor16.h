@@ -55,10 +55,16 @@ __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int 
     double row[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] = s_d16[lr][c];
-    double own_dinv = 1.0;  // 1 / L_rr of this lane's own row
     double acc[4];          // Y[r][lq + 4 i] before the final scaling by 1 / L_rr
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (lq + 4 * i == lr) ? 1.0 : 0.0;
+    // The single factor wave issues in order and is ISSUE-bound (~7 cycles per instruction), so what counts
+    // per pivot is the number of instructions: 8 on the chain (broadcast, rsq, cubic step, column scaling),
+    // 15 - j row updates and j/4 + 1 inverse updates (one v_fmac_f64_dpp each), 4 for the multiplier of the
+    // inverse.  Nothing else: the scaled column IS the factor's column (lane j: d * rsqrt(d) = L_jj, <= 1.5 ulp;
+    // no Newton-corrected copy, no select to put it in place), rows of lanes <= j are final and what the later
+    // updates do to their (upper-triangular, never read) entries does not matter, and 1 / L_rr of a lane's own
+    // row is recomputed ONCE at the end from the factor it has just written to LDS.
     static_for<0, 16>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         // lane masks are recomputed per pivot from an opaque copy of the row index: kept live
@@ -67,40 +73,43 @@ __device__ __forceinline__ int factor16(double (*s_d16)[17], double *s_inv, int 
         asm volatile("" : "+v"(lrj));
         const double d = bcast16<j>(row[j]);
         // The 128-pivot chain is the critical path of the whole panel phase.  No pivot test sits
-        // on it: a non-positive (or NaN) pivot turns 1/L_jj into NaN or a negative number and
-        // is found from that after the loop.  rsqrt = v_rsq_f64 (~2^-26) + one cubic step
-        // (<= 1 ulp), without the library's zero / infinity special cases; the multipliers use
-        // it as it is, the diagonal entry and its reciprocal (needed only by the inverse) get a
-        // Newton correction off the chain.
+        // on it: a non-positive (or NaN) pivot turns L_jj into NaN and is found from that after
+        // the loop.  rsqrt = v_rsq_f64 (~2^-26) + one cubic step (<= 1 ulp), without the library's
+        // zero / infinity special cases.
         const double y0 = __builtin_amdgcn_rsq(d);
         const double e = fma(-(y0 * d), y0, 1.0);
         const double ri = fma(y0 * e, fma(e, 0.375, 0.5), y0);
-        const double cj = row[j] * ri;
+        const double cj = row[j] * ri;   // lanes r > j: L[r][j]; lane j: L_jj
+        row[j] = cj;
         static_for<j + 1, 16>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             fnmac_bcast16<c, c == j + 1>(row[c], cj, cj);  // row[c] -= L[c][j] (lives in lane c) * L[r][j]
         });
-        double s = d * ri;
-        s = fma(0.5 * ri, fma(-s, s, d), s);
-        const double dinv = fma(ri, fma(-s, ri, 1.0), ri);
-        own_dinv = (lrj == j) ? dinv : own_dinv;
-        row[j] = (lrj == j) ? s : cj;
         // Inverse, step j: row j of Y is final (acc_j / L_jj), is broadcast from lane j of each
         // DPP row, and every lane r > j subtracts L[r][j] * Y[j][:].  Columns past j are still
         // zero in lane j, so the registers i > j/4 need no work.
-        const double m = (lrj > j) ? cj * dinv : 0.0;  // L[r][j] / L_jj below the pivot, 0 on and above it
+        const double m = (lrj > j) ? cj * ri : 0.0;  // L[r][j] / L_jj below the pivot, 0 on and above it
         static_for<0, j / 4 + 1>([&](auto ic_) {
             constexpr int i = decltype(ic_)::value;
             fnmac_bcast16<j, i == 0>(acc[i], acc[i], m);  // acc[i] -= (acc[i] of lane j) * m; lane j itself: m = 0
         });
     });
-    // first row whose pivot was not a positive finite number (lanes 0..15 hold rows 0..15)
-    const unsigned long long badmask = __ballot(!(own_dinv > 0.0) || !(own_dinv < INFINITY)) & 0xffffull;
-    const int bad = badmask ? __builtin_ctzll(badmask) + 1 : 0;
     if (lq == 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) s_d16[lr][c] = (c <= lr) ? row[c] : 0.0;
     }
+    // 1 / L_rr of this lane's own row: L_rr back from LDS (the lq == 0 lane of the same wave wrote it; LDS
+    // operations of one wave complete in order), v_rcp_f64 + two Newton steps
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double lrr = s_d16[lr][lr];
+    double own_dinv = __builtin_amdgcn_rcp(lrr);
+    own_dinv = fma(own_dinv, fma(-lrr, own_dinv, 1.0), own_dinv);
+    own_dinv = fma(own_dinv, fma(-lrr, own_dinv, 1.0), own_dinv);
+    // first row whose pivot was not a positive finite number (lanes 0..15 hold rows 0..15)
+    const unsigned long long badmask = __ballot(!(lrr > 0.0) || !(lrr < INFINITY)) & 0xffffull;
+    const int bad = badmask ? __builtin_ctzll(badmask) + 1 : 0;
     // A-operand order: register i of lane (r, q) is Linv[r][q + 4 i] (zero above the diagonal)
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_inv[i * 64 + lane] = acc[i] * own_dinv;
