@@ -42,3 +42,32 @@ def test_kind_names():
     from gp_amd import _lib
     assert _lib.KINDS == ("QQ", "QR", "RQ", "RR", "QT", "TQ", "RT", "TR", "TT")
     assert _lib._kind("TT") == 8 and _lib._kind(3) == 3
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line the GPU box produced for this code (profiles/r02_bench_c3.json) carries every key the
+    driver's contract and the tier's measurement section name, with consistent values."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.loads(open(os.path.join(root, "profiles", "r02_bench_c3.json")).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "c4"):
+        assert k in d, k
+    assert d["metric"] == "gp_logml_evals_per_sec_N16384_D3" and d["unit"] == "evals/s" and d["dtype"] == "f64"
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["achieved"] <= r["peak"] and r["traffic"] is not None and r["traffic_source"].startswith("profiles/r02_pmc_bench_c3_n16384")
+    # whole-evaluation flops cannot exceed the peak either
+    assert 16384 ** 3 / 3.0 / (d["ms_per_step"] * 1e-3) / 1e12 <= r["peak"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1
+    c4 = d["c4"]
+    assert c4["grid_points"] == 64 and c4["sharded_results_bit_identical_to_one_rank"] is True and c4["results_ok"]
