@@ -163,3 +163,32 @@ def test_beyond_baseline_sizes_blockings_agree(ctx):
         finally:
             ctx.set_option("nb_outer", 0)
         assert np.isfinite(a) and abs(a - b) <= 1e-10 * abs(a), (n, a, b)
+
+
+def test_past_2_pow_31_elements_block_diagonal_decomposition(ctx):
+    """Maximum sizes: N = 50001 (SE) and joint order 48002 (derivative GP) -- more than 2^31 matrix elements,
+    where a 32-bit element index would wrap.  No oracle or LAPACK finishes at this size, so the check is a
+    decomposition: two clusters of inputs so far apart that every cross-covariance underflows to exactly 0
+    make K block diagonal (for the joint [y, y'] matrix: up to a permutation), hence
+    logml(all) = logml(cluster 1) + logml(cluster 2), both safe-size problems; the second cluster's block
+    lies entirely beyond element 2^31."""
+    from gp_amd import synth
+    n = 50001
+    X, y = synth.synth(n, 3)
+    X = np.asfortranarray(X)
+    h = n // 2 + 3
+    X[h:, 0] += 1000.0
+    full = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+    parts = ctx.logml(np.asfortranarray(X[:h]), y[:h], 1.0, [0.3], 0.1)[0] + ctx.logml(np.asfortranarray(X[h:]), y[h:], 1.0, [0.3], 0.1)[0]
+    print("N=50001: logml %.9f vs sum of clusters %.9f, rel %.2e" % (full, parts, abs(full - parts) / abs(full)))
+    assert np.isfinite(full) and abs(full - parts) <= 1e-10 * abs(full)
+    n = 24001
+    h = n // 2 + 5
+    t = np.linspace(0, 10 * n / 8192.0, n)
+    t[h:] += 1000.0
+    ys, yd = np.sin(t), np.cos(t)
+    full = ctx.joint_logml(t, np.concatenate([ys, yd]), 1.0, 0.5, 0.1, 1e-6)[0]
+    parts = (ctx.joint_logml(t[:h], np.concatenate([ys[:h], yd[:h]]), 1.0, 0.5, 0.1, 1e-6)[0]
+             + ctx.joint_logml(t[h:], np.concatenate([ys[h:], yd[h:]]), 1.0, 0.5, 0.1, 1e-6)[0])
+    print("joint order 48002: logml %.9f vs sum of clusters %.9f, rel %.2e" % (full, parts, abs(full - parts) / abs(full)))
+    assert np.isfinite(full) and abs(full - parts) <= 1e-9 * abs(full)
