@@ -326,7 +326,7 @@ def main():
     # a time with HIP-event pairs around every covariance-build, trailing-update and panel-phase
     # launch group on the launch stream.  Done separately because concurrent lanes overlap launches,
     # which makes per-launch durations meaningless inside the throughput region.
-    kt = {"syrk": (0, 0.0, 0.0), "build": (0, 0.0, 0.0), "panel": (0, 0.0, 0.0)}
+    kt = {"syrk": (0, 0.0, 0.0), "build": (0, 0.0, 0.0), "panel": (0, 0.0, 0.0), "syrk_multi_round": (0, 0.0, 0.0)}
     seq_ms = None
     if rank == 0:
         ctx.set_option("grid_lanes", 1)
@@ -441,10 +441,11 @@ def main():
         syrk_n, syrk_ms, syrk_flops = kt["syrk"]
         build_n, build_ms, build_bytes = kt["build"]
         pan_n, pan_ms, pan_flops = kt["panel"]
+        mr_n, mr_ms, mr_flops = kt["syrk_multi_round"]
         ach = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         pach = pan_flops / (pan_ms * 1e-3) / 1e12 if pan_ms > 0 else 0.0
         chol_flops = order ** 3 / 3.0
-        nbo_auto = (lambda nf: 1024 if nf >= 12288 else 512 if nf >= 6144 else 256)(order)
+        nbo_auto = (lambda nf: 1024 if nf >= 8192 else 512 if nf >= 4608 else 256 if nf >= 3584 else 128)(order)
         build_kernel = "k_joint_cov" if args.workload == "c5" else "k_se_cov<%d>" % D
         syrk_traffic, syrk_util, syrk_src = pmc_lookup(args.workload, order, "k_gemm_nt<1>")
         line = {
@@ -470,7 +471,7 @@ def main():
                 "c5": "c5: derivative joint [y, y'] covariance, N=%d (matrix order %d), build + fp64 Cholesky "
                       "+ solve + log-det, 1 (l, sigma) point per step per GPU" % (n, 2 * n)}[args.workload],
                        "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1,
-                       "nb_outer": args.nb_outer or "auto(%d)" % nbo_auto,
+                       "nb_outer": args.nb_outer or "auto(adaptive: %d for the first block, narrower as the trailing matrix shrinks)" % nbo_auto,
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
             "launched_by": "bench.py launcher" if os.environ.get("GPMI_BENCH_LAUNCHED") else
@@ -496,6 +497,13 @@ def main():
                 "launches": int(syrk_n),
                 "avg_launch_ms": syrk_ms / max(syrk_n, 1),
                 "flops_per_launch_avg": syrk_flops / max(syrk_n, 1),
+                # subset of the above: launches of more than one round of tiles (throughput-bound; a single-round
+                # launch also factors the next diagonal block and is bounded by that ~27 us latency chain)
+                "multi_round_launches": {
+                    "launches": int(mr_n), "avg_launch_ms": mr_ms / max(mr_n, 1),
+                    "achieved": mr_flops / (mr_ms * 1e-3) / 1e12 if mr_ms > 0 else 0.0,
+                    "frac": (mr_flops / (mr_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if mr_ms > 0 else 0.0,
+                    "share_of_syrk_flops": mr_flops / syrk_flops if syrk_flops > 0 else 0.0},
             },
             "roofline_panel": {
                 "kernel": "panel phase of one outer block: k_potrf_diag4 + k_trsm_panel + k_gemm_nt<0> (in-block "

@@ -26,7 +26,7 @@ SYMBOLS = (
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
     "gpmi_interp_free", "gpmi_logml_grad", "gpmi_logml_grad_grid",
     "gpmi_seq_create", "gpmi_seq_step", "gpmi_seq_commit", "gpmi_seq_count", "gpmi_seq_destroy",
-    "gpmi_last_timing", "gpmi_kernel_timing",
+    "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_kernel_timing_ex",
 )
 # additionally exported by the probe build (libgpmi_probes.so, -DGPMI_PROBES; tools/ only)
 PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock", "gpmi_probe_fused")
@@ -180,10 +180,11 @@ class Context:
         return out
 
     def kernel_timing(self, reset=True):
-        """{category: (launches, total_ms, total_work)} for 'build' (bytes) and 'syrk' (flops)."""
-        out = np.zeros(9)
-        _chk(self._lib.gpmi_kernel_timing(self._h, int(bool(reset)), _p(out)))
-        return {"build": tuple(out[0:3]), "syrk": tuple(out[3:6]), "panel": tuple(out[6:9])}
+        """{category: (launches, total_ms, total_work)}: 'build' (bytes), 'syrk' and 'panel' (flops), 'syrk_multi_round'
+        (the trailing-update launches of more than one round of tiles, a subset of 'syrk')."""
+        out = np.zeros(12)
+        _chk(self._lib.gpmi_kernel_timing_ex(self._h, int(bool(reset)), _p(out)))
+        return {"build": tuple(out[0:3]), "syrk": tuple(out[3:6]), "panel": tuple(out[6:9]), "syrk_multi_round": tuple(out[9:12])}
 
     # ---- covariance builders (host buffers) ----------------------------------
     def se_cov(self, X, Y, alpha, ell, diag_add=0.0, flags=FULL):

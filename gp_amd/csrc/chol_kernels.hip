@@ -916,6 +916,56 @@ __device__ unsigned long long g_clk[4];
 __device__ unsigned long long g_fz[8];  // fused in-block launch, block 0: cycles in sub-tile, flag wait, diagonal body; launches
 #endif
 
+// Blocks 0 .. SUBWG - 1 of a sub-tiled fused launch (order bit 9): the 36 lower 16 x 16 sub-tiles of the
+// diagonal tile (0, 0), one per wave; block 0 then waits for the other eight on fd.ctr and factors the block.
+// The SUBWG blocks are the first of the grid -- dispatched together, so the wait cannot deadlock.
+__device__ __forceinline__ void fused_subtiles_and_diag(double (&smem)[2][2][GK][GP], int b, const double *__restrict__ A, size_t lda,
+                                                        const double *__restrict__ B, size_t ldb, double *__restrict__ C, size_t ldc,
+                                                        int K, const FuseDiag &fd)
+{
+#ifdef GPMI_PROBES
+    const unsigned long long fz0 = __builtin_amdgcn_s_memtime();
+#endif
+    {
+        const int t = b * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // sub-tile index, row-major lower triangle
+        int tm = 0;
+        while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+        const int tn = t - tm * (tm + 1) / 2;
+        gemm_sub16<true>(A, lda, B, ldb, C, ldc, K, tm * 16, tn * 16);
+    }
+    // the agent-scope stores above are complete (acknowledged by the memory side) once
+    // vmcnt drains; no cache-wide fence is needed around this hand-over
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (b) {
+        if (threadIdx.x == 0) atomicAdd(fd.ctr, 1);
+        return;
+    }
+#ifdef GPMI_PROBES
+    const unsigned long long fz1 = __builtin_amdgcn_s_memtime();
+#endif
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(fd.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < SUBWG - 1)
+            __builtin_amdgcn_s_sleep(4);
+        __hip_atomic_store(fd.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
+    }
+    __syncthreads();
+#ifdef GPMI_PROBES
+    const unsigned long long fz2 = __builtin_amdgcn_s_memtime();
+#endif
+    if (fd.nb == GPMI_NB) potrf_diag4_body<true, true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+    else potrf_diag4_body<true, false>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
+#ifdef GPMI_PROBES
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_fz[0], fz1 - fz0);
+        atomicAdd(&g_fz[1], fz2 - fz1);
+        atomicAdd(&g_fz[2], __builtin_amdgcn_s_memtime() - fz2);
+        atomicAdd(&g_fz[3], 1ull);
+        atomicAdd(&g_fz[4], (unsigned long long)K);
+    }
+#endif
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A, size_t lda,
                                                  const double *__restrict__ B, size_t ldb,
@@ -948,6 +998,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
     int ti, tj;
     if (MODE == 1) {
         int b = blockIdx.x;
+        if (order & 0x200) {  // sub-tiled fused launch: tile 0 = the next diagonal block, by the first SUBWG blocks
+            if (b < SUBWG) {
+                fused_subtiles_and_diag(smem, b, A, lda, B, ldb, C, ldc, K, fd);
+                return;
+            }
+            b -= SUBWG - 1;   // blocks SUBWG, ... are the tiles 1, 2, ...
+        }
         const int T = (M + GT - 1) / GT;
         const int TN = (N + GT - 1) / GT < T ? (N + GT - 1) / GT : T;
         if (ks.S > 1 && b >= ks.bfull) {
@@ -981,47 +1038,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         // are the tiles 1, 2, ...
         const int b = blockIdx.x;
         if (b < SUBWG) {
-#ifdef GPMI_PROBES
-            const unsigned long long fz0 = __builtin_amdgcn_s_memtime();
-#endif
-            {
-                const int t = b * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // sub-tile index, row-major lower triangle
-                int tm = 0;
-                while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
-                const int tn = t - tm * (tm + 1) / 2;
-                gemm_sub16<true>(A, lda, B, ldb, C, ldc, K, tm * 16, tn * 16);
-            }
-            // the agent-scope stores above are complete (acknowledged by the memory side) once
-            // vmcnt drains; no cache-wide fence is needed around this hand-over
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (b) {
-                if (threadIdx.x == 0) atomicAdd(fd.ctr, 1);
-                return;
-            }
-#ifdef GPMI_PROBES
-            const unsigned long long fz1 = __builtin_amdgcn_s_memtime();
-#endif
-            if (threadIdx.x == 0) {
-                while (__hip_atomic_load(fd.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < SUBWG - 1)
-                    __builtin_amdgcn_s_sleep(4);
-                __hip_atomic_store(fd.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch is stream-ordered
-            }
-            __syncthreads();
-#ifdef GPMI_PROBES
-            const unsigned long long fz2 = __builtin_amdgcn_s_memtime();
-#endif
-            if (fd.nb == GPMI_NB) potrf_diag4_body<true, true>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
-            else potrf_diag4_body<true, false>(&smem[0][0][0][0], C, ldc, fd.nb, fd.Fp, fd.info, fd.col0);
-#ifdef GPMI_PROBES
-            if (threadIdx.x == 0) {
-                atomicAdd(&g_fz[0], fz1 - fz0);
-                atomicAdd(&g_fz[1], fz2 - fz1);
-                atomicAdd(&g_fz[2], __builtin_amdgcn_s_memtime() - fz2);
-                atomicAdd(&g_fz[3], 1ull);
-                atomicAdd(&g_fz[4], (unsigned long long)K);
-            }
-#endif
+            fused_subtiles_and_diag(smem, b, A, lda, B, ldb, C, ldc, K, fd);
             return;
         }
         const int gx = (M + GT - 1) / GT;
@@ -1648,9 +1665,12 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
 {
     t->syrk_order = 0;
     t->stagger = (2 << 16) | 4;
-    t->fuse_diag = 7;
+    t->fuse_diag = 15;
     t->diag_waves = 4;
-    t->nb_adapt = 0;
+    t->nb_adapt = 1;
+    t->nb_thr[0] = 8192;
+    t->nb_thr[1] = 4608;
+    t->nb_thr[2] = 3584;
     t->ksplit = 1;
     t->ksplit_max = 100;
     t->block_recursive = 1;
@@ -1700,7 +1720,8 @@ void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t ld
 // 24.55 / 4.02 -- with both, no one-workgroup kernel is left that has to find a free CU next to the
 // other lanes' updates.  One evaluation at a time: neutral (the block's tile sits on the critical
 // path either way).
-// (tune.fuse_diag, default 7; bit 2: sub-tiled diagonal tile in the fused in-block GEMMs)
+// (tune.fuse_diag, default 15; bit 2: sub-tiled diagonal tile in the fused in-block GEMMs; bit 3: the same in
+// single-round trailing SYRK launches)
 
 // C -= A B^T with the default kernel and the diagonal block at C's origin factored by the
 // workgroup of tile (0, 0).  false: this configuration cannot fuse (caller launches the
@@ -1720,8 +1741,11 @@ static bool launch_gemm_nt_fused(const gpmi_ctx *c, hipStream_t s, const double 
 
 // tune.diag_waves  4 (default): k_potrf_diag4 (3 tile waves + factor wave, two barriers per block column; fits beside a
 //                  resident SYRK workgroup), 5: k_potrf_diag (4 tile waves + factor wave, three barriers)
-// tune.nb_adapt    1: auto outer-block width chosen per block from the columns still to factor (measured: -0.2 ms
-//                  sequential at N = 16384, nothing with lanes)
+// tune.nb_adapt    1 (default): the auto outer-block width is re-chosen per block from the order of the matrix still to
+//                  update (tune.nb_thr: >= 8192 -> 1024 columns, >= 4608 -> 512, >= 3584 -> 256, below -> 128): the last
+//                  blocks of a large matrix are a small matrix.  Pays since single-round trailing updates carry the next
+//                  diagonal block (fuse_diag bit 3): N = 8192 5.63 -> 5.35 ms one at a time, 3.54 -> 3.38 on lanes;
+//                  N = 4096 1.54 -> 1.47; N = 16384 28.0 -> 27.4 / 23.3 -> 23.1 (thresholds swept in steps of 1024)
 // tune.ksplit      quadrant split of the tail-round tiles of a SYRK launch (see KSplit) ...
 // tune.ksplit_max  ... when at most this many tiles are left for the last round.  Whole tiles of a round this thin run
 // alone on their CUs (~115 us at K = 1024 instead of ~250 us shared); four quadrant workgroups take
@@ -1770,7 +1794,18 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
     // only in launches of more than one round of tiles, where workgroup 0's extra 27 us do not
     // lengthen the kernel
     const int slots = 2 * (ncu > 0 ? ncu : 256);
-    const bool fuse = fd && fd->Fp && (c->tune.fuse_diag & 2) && syrk_order == 0 && ntiles > slots;
+    bool fuse = fd && fd->Fp && (c->tune.fuse_diag & 2) && syrk_order == 0 && ntiles > slots;
+    // Single-round launches: the next diagonal block rides along as well, sub-tiled like in the in-block products
+    // (fused_subtiles_and_diag) -- its 36 sub-tiles and the block's factorisation (~6 + 21 us) run beside the other
+    // tiles instead of in a kernel of their own behind the launch (tune.fuse_diag bit 3).
+    int ord = syrk_order;
+    FuseDiag fdl = fuse ? *fd : FuseDiag{};
+    if (!fuse && fd && fd->Fp && (c->tune.fuse_diag & 8) && syrk_order == 0 && M >= GT && N >= GT && K % 64 == 0 && c->d_ctr) {
+        fuse = true;
+        ord |= 0x200;
+        fdl = *fd;
+        fdl.ctr = c->d_ctr + 8;
+    }
     KSplit ks{};
     int grid = ntiles;
     if (c->tune.ksplit && syrk_order == 0 && K % GK == 0) {
@@ -1783,13 +1818,14 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
         // valid rows are multiplied (1/8 of the work).
         const int vlast = M - (T - 1) * GT;
         if (T > 1 && vlast <= 64 && ntiles - TN < first) first = ntiles - TN;  // the last tile row has TN tiles
+        if ((ord & 0x200) && first < 1) first = 1;  // tile 0 belongs to the sub-tile blocks
         if (first < ntiles) {
             ks = KSplit{first, 4};
             grid = first + 4 * (ntiles - first);
         }
     }
-    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(grid), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, syrk_order, stg,
-                       fuse ? *fd : FuseDiag{}, ks);
+    if (ord & 0x200) grid += SUBWG - 1;
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(grid), 256, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, ord, stg, fdl, ks);
     return fuse;
 }
 
@@ -1905,8 +1941,10 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     // trapezoid in W; the trailing [nfac, ncol) part receives the Schur complement.
     // outer block width: K of the trailing update.  Wider blocks cut the C traffic and the
     // number of epilogues once the trailing matrix is large; 256 keeps the panel phase short.
-    auto nbo_for = [](int cols) { return cols >= 12288 ? 1024 : (cols >= 6144 ? 512 : 256); };
-    const int NBO = c->nb_outer > 0 ? c->nb_outer : nbo_for(nfac);
+    auto nbo_for = [c](int cols) {
+        return cols >= c->tune.nb_thr[0] ? 1024 : (cols >= c->tune.nb_thr[1] ? 512 : (cols >= c->tune.nb_thr[2] ? 256 : 128));
+    };
+    const int NBO = c->nb_outer > 0 ? c->nb_outer : nbo_for(ncol);
     // look-ahead needs at least three outer blocks to pay, a second stream, and the block's packed
     // factors in the ring (or all kept)
     bool la = c->lookahead > 0 && nfac >= 3 * NBO && (Fpack_all || NBO / GPMI_NB <= GPMI_FPACK_SLOTS);
@@ -1917,11 +1955,11 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     }
     if (!la) {
         hipStream_t s = c->stream;
-        // auto width follows the columns still to factor (tune.nb_adapt): the last blocks of a large
-        // matrix are a small matrix, whose few trailing tiles do not fill the chip at K = 1024
+        // auto width follows the order of the matrix still to update (tune.nb_adapt): the last blocks of a
+        // large matrix are a small matrix, whose few trailing tiles do not fill the chip at K = 1024
         bool diag_done = false;
         for (int ko = 0, nbo = NBO; ko < nfac; ko += nbo) {
-            nbo = (c->nb_outer > 0 || !c->tune.nb_adapt) ? NBO : nbo_for(nfac - ko);
+            nbo = (c->nb_outer > 0 || !c->tune.nb_adapt) ? NBO : nbo_for(ncol - ko);
             const int ke = (ko + nbo < nfac) ? ko + nbo : nfac;
             kt_begin(c, 2, s);
             panel_rows(c, W, ld, d_info, Fpack_all, ko, ke, nbo, 0, M, true, s, diag_done);
@@ -1940,7 +1978,11 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             diag_done = launch_syrk_lower(c, s, W + (size_t)ke + (size_t)ko * ld, ld, W + (size_t)ke + (size_t)ke * ld, ld,
                                           M - ke, ncol - ke, ke - ko, c->d_ctr, c->ncu, 0, &fd);
             // algorithmic flops: lower triangle (incl. diagonal) of the square part + extra rows
-            kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(ke - ko), s);
+            {   // flag: more than one round of tiles (throughput-bound launch)
+                const int T = (M - ke + GT - 1) / GT, TNf = (ncol - ke + GT - 1) / GT, TN = TNf < T ? TNf : T;
+                kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)(ke - ko), s,
+                       syrk_grid(T, TN, 0) > 2 * (c->ncu > 0 ? c->ncu : 256));
+            }
         }
     } else {
         // Look-ahead over outer blocks on TWO streams.  With U(j) the trailing update by block j,

@@ -62,6 +62,8 @@ extern "C" int gpmi_device_count(int *count)
 // ---- per-kernel event timing --------------------------------------------------
 struct KTimer {
     std::vector<hipEvent_t> a[3], b[3];
+    std::vector<double> w[3];     // work of each bracket
+    std::vector<char> flag[3];    // caller's mark (category 1: launch of more than one round of tiles)
     size_t used[3] = {0, 0, 0};
     double work[3] = {0, 0, 0};
 };
@@ -76,15 +78,19 @@ void kt_begin(gpmi_ctx *c, int cat, hipStream_t st)
         hipEventCreate(&e1);
         k->a[cat].push_back(e0);
         k->b[cat].push_back(e1);
+        k->w[cat].push_back(0.0);
+        k->flag[cat].push_back(0);
     }
     hipEventRecord(k->a[cat][k->used[cat]], st ? st : c->stream);
 }
 
-void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t st)
+void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t st, int flag)
 {
     if (!c->ktiming) return;
     KTimer *k = (KTimer *)c->ktimer;
     hipEventRecord(k->b[cat][k->used[cat]], st ? st : c->stream);
+    k->w[cat][k->used[cat]] = work;
+    k->flag[cat][k->used[cat]] = (char)flag;
     k->used[cat]++;
     k->work[cat] += work;
 }
@@ -356,6 +362,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     }
     if (!strcmp(name, "nb_adapt")) {
         c->tune.nb_adapt = value != 0;
+        return 0;
+    }
+    if (!strcmp(name, "nb_thr1024") || !strcmp(name, "nb_thr512") || !strcmp(name, "nb_thr256")) {
+        if (value < 0) return gpmi_fail(GPMI_EARG, "%s must be >= 0", name);
+        c->tune.nb_thr[name[6] == '1' ? 0 : (name[6] == '5' ? 1 : 2)] = value;
         return 0;
     }
     if (!strcmp(name, "syrk_order")) {
@@ -2088,26 +2099,35 @@ extern "C" int gpmi_last_timing(gpmi_ctx *c, double *ms3)
     return 0;
 }
 
-// out9[3*cat + 0..2] = launches, total ms, total work (bytes for cat 0, flops for 1 and 2) since
-// the last reset; synchronises the stream.
-extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
+// out[3*cat + 0..2] = launches, total ms, total work (bytes for cat 0, flops for 1 and 2) since
+// the last reset; with n_out = 12, out[9..11] = the same for the trailing-update launches of more than one round
+// of tiles (the throughput-bound subset of category 1; the single-round ones carry the next diagonal block's
+// latency chain).  Synchronises the stream.
+static int kernel_timing(gpmi_ctx *c, int reset, double *out, int n_out)
 {
-    ENTER(c);
     if (!c->ktimer) return gpmi_fail(GPMI_EARG, "kernel timing was never enabled");
     KTimer *k = (KTimer *)c->ktimer;
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (out9) {
+    if (out) {
+        double sub[3] = {0.0, 0.0, 0.0};
         for (int cat = 0; cat < 3; ++cat) {
             double tot = 0.0;
             for (size_t i = 0; i < k->used[cat]; ++i) {
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, k->a[cat][i], k->b[cat][i]));
                 tot += ms;
+                if (cat == 1 && k->flag[cat][i]) {
+                    sub[0] += 1.0;
+                    sub[1] += ms;
+                    sub[2] += k->w[cat][i];
+                }
             }
-            out9[3 * cat] = (double)k->used[cat];
-            out9[3 * cat + 1] = tot;
-            out9[3 * cat + 2] = k->work[cat];
+            out[3 * cat] = (double)k->used[cat];
+            out[3 * cat + 1] = tot;
+            out[3 * cat + 2] = k->work[cat];
         }
+        if (n_out >= 12)
+            for (int i = 0; i < 3; ++i) out[9 + i] = sub[i];
     }
     if (reset)
         for (int cat = 0; cat < 3; ++cat) {
@@ -2115,6 +2135,18 @@ extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
             k->work[cat] = 0.0;
         }
     return 0;
+}
+
+extern "C" int gpmi_kernel_timing(gpmi_ctx *c, int reset, double *out9)
+{
+    ENTER(c);
+    return kernel_timing(c, reset, out9, 9);
+}
+
+extern "C" int gpmi_kernel_timing_ex(gpmi_ctx *c, int reset, double *out12)
+{
+    ENTER(c);
+    return kernel_timing(c, reset, out12, 12);
 }
 
 #ifdef GPMI_PROBES

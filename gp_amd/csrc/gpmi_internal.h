@@ -23,9 +23,10 @@ struct SeParams {            // squared-exponential hyper-parameters, kernel-arg
 struct gpmi_tuning {
     int syrk_order;       // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
     int stagger;          // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup of a CU pair
-    int fuse_diag;        // bit 0: in-block GEMMs, bit 1: trailing SYRK, bit 2: sub-tiled diagonal tile
+    int fuse_diag;        // bit 0: in-block GEMMs, bit 1: trailing SYRK (multi-round), bit 2: sub-tiled diagonal tile, bit 3: single-round SYRK (sub-tiled)
     int diag_waves;       // 4: k_potrf_diag4 (default), 5: k_potrf_diag
-    int nb_adapt;
+    int nb_adapt;         // outer-block width re-chosen per block from the order of the matrix still to update
+    int nb_thr[3];        // ... >= nb_thr[0]: 1024 columns, >= nb_thr[1]: 512, >= nb_thr[2]: 256, below: 128
     int ksplit, ksplit_max;
     int block_recursive;
     int se_nt;            // non-temporal stores in k_se_cov<>
@@ -88,7 +89,7 @@ struct gpmi_ctx {
 
 // event-pair recorder; begin/end bracket one launch on the context's stream
 void kt_begin(gpmi_ctx *c, int cat, hipStream_t s = nullptr);
-void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t s = nullptr);
+void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t s = nullptr, int flag = 0);
 int gpmi_lookahead_streams(gpmi_ctx *c);  // two concurrently dispatching streams for the look-ahead (calibrated, or a panel stream)
 
 // ---- error plumbing -------------------------------------------------------

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GPMI_VERSION 200
+#define GPMI_VERSION 201
 
 /* the ABI: the ONLY symbols libgpmi.so exports (it is built with -fvisibility=hidden) */
 #define GPMI_API __attribute__((visibility("default")))
@@ -85,7 +85,7 @@ GPMI_API int gpmi_sync(gpmi_ctx *ctx);
 GPMI_API int gpmi_reserve(gpmi_ctx *ctx, int n_max);
 /* algorithm switches of THIS context (never process-global): "nb_outer" (outer panel width, multiple
  * of 128, 0 = auto), "grid_lanes", "lookahead", "fuse_diag", "ksplit", "block_recursive", "diag_waves",
- * "syrk_order", "stagger", "se_nt", "nb_adapt", "calibrate", "timing", "kernel_timing"; unknown
+ * "syrk_order", "stagger", "se_nt", "nb_adapt", "nb_thr1024", "nb_thr512", "nb_thr256", "calibrate", "timing", "kernel_timing"; unknown
  * names return GPMI_EARG */
 GPMI_API int gpmi_set_option(gpmi_ctx *ctx, const char *name, int value);
 
@@ -290,6 +290,10 @@ GPMI_API int gpmi_last_timing(gpmi_ctx *ctx, double *ms3);
  * trailing-update SYRK launch (1; work = algorithmic flops) on the context's stream.
  * out9[3*cat + 0..2] = launches, total ms, total work since the last reset. */
 GPMI_API int gpmi_kernel_timing(gpmi_ctx *ctx, int reset, double *out9);
+/* The same with out12[9..11] = launches, total ms, total flops of the trailing-update launches of more than one
+ * round of tiles -- the throughput-bound subset of category 1 (a single-round launch carries the next diagonal
+ * block's factorisation and is bounded by that latency chain). */
+GPMI_API int gpmi_kernel_timing_ex(gpmi_ctx *ctx, int reset, double *out12);
 
 /* ---- probes: tools/ only ------------------------------------------------
  * Built into libgpmi_probes.so (-DGPMI_PROBES: `python -m gp_amd._build --probes`), never into the

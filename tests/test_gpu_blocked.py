@@ -86,7 +86,7 @@ OPTION_SETS = [{}, {"fuse_diag": 0}, {"ksplit": 0, "block_recursive": 0}, {"nb_o
 
 
 def _with_options(ctx, opts, fn):
-    defaults = {"fuse_diag": 7, "ksplit": 1, "block_recursive": 1, "nb_outer": 0}
+    defaults = {"fuse_diag": 15, "ksplit": 1, "block_recursive": 1, "nb_outer": 0}
     try:
         for k, v in opts.items():
             ctx.set_option(k, v)

@@ -130,14 +130,14 @@ def test_options_do_not_change_results_beyond_rounding(ctx, orc):
     base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     vals = []
     for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("lookahead", 1), ("lookahead", 0), ("syrk_order", 1),
-                   ("diag_waves", 5), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 1)):
+                   ("diag_waves", 5), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 0)):
         ctx.set_option(opt, v)
         try:
             vals.append(ctx.logml(X, y, 1.0, [0.3], 0.1)[0])
         finally:
             ctx.set_option("nb_outer", 0); ctx.set_option("lookahead", -1); ctx.set_option("syrk_order", 0)
             ctx.set_option("diag_waves", 4); ctx.set_option("ksplit", 1); ctx.set_option("stagger", (2 << 16) | 4)
-            ctx.set_option("se_nt", 1); ctx.set_option("nb_adapt", 0)
+            ctx.set_option("se_nt", 1); ctx.set_option("nb_adapt", 1)
     assert all(abs(v - base) <= 1e-10 * abs(base) for v in vals), (base, vals)
 
 
@@ -151,7 +151,7 @@ def test_options_are_per_context(ctx, orc):
         a = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
         b = other.logml(X, y, 1.0, [0.3], 0.1)[0]
     finally:
-        ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 7); ctx.set_option("block_recursive", 1)
+        ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 15); ctx.set_option("block_recursive", 1)
     c = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     other.close()
     assert b == c                       # `other` ran the default algorithm, bit for bit
@@ -175,7 +175,7 @@ def test_grid_lanes_match_single_evaluations(ctx, orc):
 @pytest.mark.parametrize("n,nbo", [(2500, 1024), (1333, 512), (1153, 0)])
 def test_fused_diagonal_modes_agree(ctx, orc, n, nbo):
     """The fused look-ahead variants (diagonal block factored inside the update that completes it;
-    its tile cut into three sub-tiles on three CUs; option fuse_diag bits 0..2) and the recursive /
+    its tile cut into three sub-tiles on three CUs; option fuse_diag bits 0..3: in-block products, multi-round and single-round trailing updates) and the recursive /
     fixed-level in-block blockings are re-orderings of the same factorisation: every combination
     must give the LAPACK result (1e-10 relative on logml, far inside the 1e-8 bar), also with
     ragged last panels and a forced 1024-wide outer block (K = 512 sub-tiles)."""
@@ -188,12 +188,12 @@ def test_fused_diagonal_modes_agree(ctx, orc, n, nbo):
         ctx.set_option("nb_outer", nbo)
         for rec in (1, 0):
             ctx.set_option("block_recursive", rec)
-            for mode in (0, 1, 2, 3, 7):
+            for mode in (0, 1, 2, 3, 7, 8, 15):
                 ctx.set_option("fuse_diag", mode)
                 got = ctx.logml(X, y, 1.0, [0.2], 0.1)
                 assert abs(got[0] - want) <= 1e-10 * abs(want), (rec, mode, got[0], want)
         # a non-PD matrix is still reported at the right order through the fused paths
-        ctx.set_option("fuse_diag", 7); ctx.set_option("block_recursive", 1)
+        ctx.set_option("fuse_diag", 15); ctx.set_option("block_recursive", 1)
         A = K.copy(); k = 1100 if n > 1200 else 300
         A[k, k] = -1.0
         import gp_amd
@@ -201,4 +201,4 @@ def test_fused_diagonal_modes_agree(ctx, orc, n, nbo):
             ctx.potrf(A)
         assert e.value.order == k + 1
     finally:
-        ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 7); ctx.set_option("block_recursive", 1)
+        ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 15); ctx.set_option("block_recursive", 1)
