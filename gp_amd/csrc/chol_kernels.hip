@@ -1077,67 +1077,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
 }
 
 #ifdef GPMI_PROBES  // A/B kernels of tools/ (libgpmi_probes.so); the product library ships without them
-// Persistent SYRK: at most two workgroups per CU are launched and each pulls tiles from a
-// counter until none is left.
-//  * Software CU reservation: a workgroup that finds itself on CU 0 of shader engine 0 of its
-//    XCD (8 CUs on MI355X) retires at once, as long as the launch's exit budget lasts; with no
-//    further workgroups to dispatch those CUs stay empty for the whole update.  The panel
-//    kernels of a concurrent stream -- above all the diagonal-block kernel, which needs a whole
-//    CU's LDS and would otherwise wait for a CU to drain by chance while trailing-update
-//    workgroups refill every slot that frees up -- start there without delay.  (The CU-mask
-//    stream API does the same but its queues dispatch markedly slower.)
-//  * A second update queued behind this one gets the CUs as this one's workgroups run out of
-//    tiles: tails overlap, full-speed phases do not interleave.
-// ctr[0] tile counter, ctr[1] retired workgroups, ctr[2] early exits; the last workgroup out
-// zeroes them for the next launch (launches sharing ctr are stream-ordered).
-__global__ __launch_bounds__(256, 2) void k_syrk_persist(const double *__restrict__ P, size_t ldp,
-                                                      double *__restrict__ C, size_t ldc, int M, int N, int K,
-                                                      int order, int stagger, int ntiles, int exit_budget,
-                                                      int *__restrict__ ctr)
-{
-    __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
-    __shared__ int s_next;
-    const int dbg = stagger >> 24;
-    bool leave = false;
-    if (exit_budget > 0) {
-        if (threadIdx.x == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID, all 32 bits
-            const bool reserved_cu = ((hw >> 8) & 0xf) == 0 && ((hw >> 12) & 0x1) == 0 && ((hw >> 13) & 0x7) == 0;
-            s_next = (reserved_cu && atomicAdd(&ctr[2], 1) < exit_budget) ? 1 : 0;
-        }
-        __syncthreads();
-        leave = s_next != 0;
-        __syncthreads();
-    }
-    if (!leave) {
-        stagger_start(smem, stagger);
-        const int T = (M + GT - 1) / GT;
-        for (;;) {
-            if (threadIdx.x == 0) s_next = atomicAdd(&ctr[0], 1);
-            __syncthreads();
-            const int b = __builtin_amdgcn_readfirstlane(s_next);  // wave-uniform: tile indices stay in SGPRs
-            __syncthreads();
-            if (b >= ntiles) break;
-            int ti, tj;
-            if (!syrk_tile(b, T, T, order, ti, tj)) continue;
-            // opaque copy of the thread index: keeps the lane-derived addresses of one tile from being
-            // hoisted out of the loop, where they would sit on top of the 250-register tile body
-            int tid = (int)threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            gemm_tile<1>(smem, P, ldp, P, ldp, C, ldc, M, N, K, ti, tj, dbg, tid);
-        }
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&ctr[1], 1) == (int)gridDim.x - 1) {
-            ctr[0] = 0;
-            ctr[2] = 0;
-            __threadfence();
-            ctr[1] = 0;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // GEMM NT v2: same 128x128 tile and LDS image, 8 waves (2 m x 4 n, 64 x 32 outputs per
 // wave = 8 accumulator tiles) so that 64 VGPRs are free to PREFETCH the wave's share of the
@@ -1157,7 +1096,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const double *__restrict__ A, 
     __shared__ __attribute__((aligned(16))) double smem[2][2][GK][GP];
     int ti, tj;
     if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, (M + GT - 1) / GT, order, ti, tj)) return;
+        const int Tr = (M + GT - 1) / GT, Tc = (N + GT - 1) / GT;  // M = N + 1 (augmented row): a trapezoid
+        if (!syrk_tile(blockIdx.x, Tr, Tc < Tr ? Tc : Tr, order, ti, tj)) return;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1331,7 +1271,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm9(const double *__restrict__ A, 
     __shared__ __attribute__((aligned(16))) double smem[3][2][GK][GP];
     int ti, tj;
     if (MODE == 1) {
-        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, (M + GT - 1) / GT, order, ti, tj)) return;
+        const int Tr = (M + GT - 1) / GT, Tc = (N + GT - 1) / GT;  // M = N + 1 (augmented row): a trapezoid
+        if (!syrk_tile(blockIdx.x, Tr, Tc < Tr ? Tc : Tr, order, ti, tj)) return;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1677,7 +1618,6 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->se_nt = 1;
     t->gemm_variant = 3;
     t->rect_auto = 0;
-    t->syrk_persist = 0;
 }
 
 void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
@@ -1776,15 +1716,6 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
     }
     if (c->tune.gemm_variant == 1) {
         hipLaunchKernelGGL(k_gemm8<1>, dim3(ntiles), 512, 0, s, P, ldp, P, ldp, C, ldc, M, N, K, syrk_order);
-        return false;
-    }
-    if (c->tune.syrk_persist && ctr) {
-        const int slots = 2 * (ncu > 0 ? ncu : 256);
-        const int grid = ntiles < slots ? ntiles : slots;
-        // reservation only for launches that would otherwise hold every CU for a long time
-        const int budget = (c->tune.syrk_persist == 2 && ntiles >= 2 * slots) ? 16 : 0;
-        hipLaunchKernelGGL(k_syrk_persist, dim3(grid), 256, 0, s, P, ldp, C, ldc, M, N, K, syrk_order, stg, ntiles,
-                           budget, ctr);
         return false;
     }
 #else

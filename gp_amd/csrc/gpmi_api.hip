@@ -378,10 +378,6 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->tune.rect_auto = value;
         return 0;
     }
-    if (!strcmp(name, "syrk_persist")) {
-        c->tune.syrk_persist = value;
-        return 0;
-    }
     if (!strcmp(name, "gemm_variant")) {
         c->tune.gemm_variant = value;
         return 0;

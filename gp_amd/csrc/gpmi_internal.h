@@ -30,7 +30,7 @@ struct gpmi_tuning {
     int ksplit, ksplit_max;
     int block_recursive;
     int se_nt;            // non-temporal stores in k_se_cov<>
-    int gemm_variant, rect_auto, syrk_persist;  // A/B kernels: honoured by the probe build (-DGPMI_PROBES) only
+    int gemm_variant, rect_auto;  // A/B kernels: honoured by the probe build (-DGPMI_PROBES) only
 };
 void gpmi_tuning_defaults(gpmi_tuning *t);
 

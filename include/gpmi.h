@@ -298,7 +298,7 @@ GPMI_API int gpmi_kernel_timing_ex(gpmi_ctx *ctx, int reset, double *out12);
 /* ---- probes: tools/ only ------------------------------------------------
  * Built into libgpmi_probes.so (-DGPMI_PROBES: `python -m gp_amd._build --probes`), never into the
  * shipped libgpmi.so: micro-benchmarks, the A/B kernel variants and their option names
- * (gemm_variant, syrk_persist, rect_auto, debug_topology). */
+ * (gemm_variant, rect_auto, debug_topology). */
 #ifdef GPMI_PROBES
 /* Stand-alone trailing-update (SYRK, lower) launch on synthetic data, C(m x m) -= P P^T with
  * P m x k: average ms per launch over `reps` back-to-back launches (HIP events). */

@@ -10,7 +10,6 @@ gvs = [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 ctx.set_option("syrk_order", int(sys.argv[5]) if len(sys.argv) > 5 else 0)
 staggers = [int(x) for x in (sys.argv[6].split(",") if len(sys.argv) > 6 else ["0"])]
-ctx.set_option("syrk_persist", int(sys.argv[7]) if len(sys.argv) > 7 else 0)
 for gv, stg in [(g, s_) for g in gvs for s_ in staggers]:
     ctx.set_option("gemm_variant", gv)
     ctx.set_option("stagger", stg)
