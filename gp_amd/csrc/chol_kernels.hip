@@ -1461,6 +1461,105 @@ __global__ __launch_bounds__(512) void k_pack_factors(const double *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// One right-hand side against a given factor: t = L^-1 k (forward substitution), the whitened kernel row of
+// the sequential sampler and mdivide_left_tri_low.  The factor is read ONCE (4 n^2 bytes: HBM-bound); what is
+// sequential is the chain of the n / 128 diagonal blocks.  Done through the panel kernels a one-row solve is
+// 2 n / 128 dependent launches (4.2 ms at n = 16384); here it is ONE launch:
+//   workgroup w owns the 128 unknowns of block-row w.  For j = 0 .. w - 1 it takes the 128 x 128 block
+//   L[w, j] -- its loads are issued BEFORE it waits for t_j -- multiplies it with t_j as soon as workgroup j
+//   has published it, and after j = w - 1 applies the inverse of its diagonal block (k_diag_inv_t) to
+//   k_w - sum_j L[w, j] t_j and publishes t_w.
+// Publication needs no flag: the output vector is pre-filled with an all-ones bit pattern (a NaN no
+// arithmetic produces: a computed NaN is stored as the canonical quiet NaN), every consumer thread polls ITS
+// element with agent-scope loads until it is no longer the pattern, and 64-bit agent-scope stores are
+// single-copy atomic.  A workgroup waits only for workgroups of lower index, which are dispatched before it:
+// the waits cannot deadlock, whatever the number of resident workgroups.
+// Sums in a fixed order: deterministic.
+// ---------------------------------------------------------------------------
+constexpr int TSV = 128;
+constexpr unsigned long long TSV_EMPTY = ~0ull;
+
+// Dinv[w]: the inverse of the w-th 128 x 128 diagonal block of L, column-major with leading dimension 128
+// (element (r, c) at r + 128 c; zero above the diagonal; identity rows / columns past the matrix order).
+// From X = I solved against the block by the panel kernel (X L^-T = L^-T), transposed.
+__global__ __launch_bounds__(256) void k_eye_blocks(double *__restrict__ X, int nblk)
+{
+    const int w = blockIdx.x;
+    for (int e = threadIdx.x; e < TSV * TSV; e += 256) X[(size_t)w * TSV * TSV + e] = ((e & (TSV - 1)) == (e >> 7)) ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(256) void k_transpose_blocks(const double *__restrict__ X, double *__restrict__ D)
+{
+    __shared__ double t[16][17];
+    const size_t base = (size_t)blockIdx.x * TSV * TSV;
+    const int bi = (blockIdx.y & 7) * 16, bj = (blockIdx.y >> 3) * 16;
+    const int a = threadIdx.x & 15, b = threadIdx.x >> 4;
+    t[b][a] = X[base + (bi + a) + (size_t)(bj + b) * TSV];
+    __syncthreads();
+    D[base + (bj + a) + (size_t)(bi + b) * TSV] = t[a][b];
+}
+
+__global__ __launch_bounds__(256) void k_trsv_wave(const double *__restrict__ L, size_t ldl, int n,
+                                                   const double *__restrict__ k, double *__restrict__ t,
+                                                   const double *__restrict__ Dinv)
+{
+    __shared__ double ts[TSV];
+    __shared__ double red[2][TSV];
+    const int w = blockIdx.x, tid = threadIdx.x, r = tid & (TSV - 1), h = tid >> 7;
+    const int row = w * TSV + r;
+    const bool rok = row < n;
+    const size_t rowc = (size_t)(rok ? row : n - 1);
+    // this thread's 64 entries of row r of the inverse diagonal block (columns 64 h ...)
+    double Dr[64];
+    {
+        const double *d = Dinv + (size_t)w * TSV * TSV + r + (size_t)(64 * h) * TSV;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) Dr[q] = d[(size_t)q * TSV];
+    }
+    const double kv = rok ? k[row] : 0.0;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < w; ++j) {
+        double Lr[64];
+        const double *p = L + rowc + (size_t)(j * TSV + 64 * h) * ldl;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) Lr[q] = p[(size_t)q * ldl];
+        if (tid < TSV) {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(t) + (size_t)j * TSV + tid;
+            unsigned long long u;
+            while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == TSV_EMPTY) __builtin_amdgcn_s_sleep(1);
+            ts[tid] = __longlong_as_double((long long)u);
+        }
+        __syncthreads();
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 64; q += 2) {
+            a0 = fma(Lr[q], ts[64 * h + q], a0);
+            a1 = fma(Lr[q + 1], ts[64 * h + q + 1], a1);
+        }
+        acc += a0 + a1;
+        __syncthreads();  // ts is rewritten in the next round
+    }
+    red[h][r] = acc;
+    __syncthreads();
+    if (h == 0) ts[r] = rok ? kv - (red[0][r] + red[1][r]) : 0.0;
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; q += 2) {  // lower triangle only: a NaN further down the right-hand side stays there
+        if (64 * h + q <= r) a0 = fma(Dr[q], ts[64 * h + q], a0);
+        if (64 * h + q + 1 <= r) a1 = fma(Dr[q + 1], ts[64 * h + q + 1], a1);
+    }
+    __syncthreads();
+    red[h][r] = a0 + a1;
+    __syncthreads();
+    if (h == 0 && rok) {
+        double v = red[0][r] + red[1][r];
+        if (v != v) v = __longlong_as_double(0x7ff8000000000000ll);  // never the "not yet" pattern
+        __hip_atomic_store(t + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // out[j] = scale * W[row, col0 + j]
 __global__ void k_get_row(const double *__restrict__ W, size_t ld, int row, int col0, int m, double scale,
                           double *__restrict__ out)
@@ -2056,6 +2155,33 @@ int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "trsm launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// Dinv (ceil(n / 128) blocks of 128 x 128 doubles): inverses of L's diagonal blocks from its packed factors;
+// tmp: the same size of scratch
+void launch_diag_inverses(hipStream_t s, const double *Fpack_all, int n, double *Dinv, double *tmp)
+{
+    if (n <= 0) return;
+    const int nblk = (n + TSV - 1) / TSV;
+    hipLaunchKernelGGL(k_eye_blocks, dim3(nblk), 256, 0, s, tmp, nblk);
+    for (int w = 0; w < nblk; ++w) {
+        const int kb = (n - w * TSV < TSV) ? n - w * TSV : TSV;
+        hipLaunchKernelGGL(k_trsm_panel, dim3(2), 256, 0, s, tmp + (size_t)w * TSV * TSV, (size_t)TSV, 0, TSV, kb,
+                           Fpack_all + (size_t)w * GPMI_FPACK);
+    }
+    hipLaunchKernelGGL(k_transpose_blocks, dim3(nblk, 64), 256, 0, s, tmp, Dinv);
+}
+
+// t = L^-1 k (k, t: n contiguous doubles, different buffers) in one launch; Dinv from launch_diag_inverses
+int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *k, double *t, const double *Dinv)
+{
+    if (n <= 0) return 0;
+    hipError_t e = hipMemsetAsync(t, 0xff, (size_t)n * sizeof(double), s);  // "not yet" in every element
+    if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_trsv_wave, dim3((n + TSV - 1) / TSV), 256, 0, s, L, ldl, n, k, t, Dinv);
+    e = hipGetLastError();
+    if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "trsv launch failed: %s", hipGetErrorString(e));
     return 0;
 }
 

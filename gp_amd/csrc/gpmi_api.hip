@@ -718,8 +718,8 @@ extern "C" int gpmi_trmv_lower(gpmi_ctx *c, const double *L, int n, int ldl, con
     return 0;
 }
 
-// z = L^-1 b for a given lower factor (mdivide_left_tri_low): z^T = b^T L^-T as a one-row
-// right-solve with the panel kernels; the block factors are packed from L itself.
+// z = L^-1 b for a given lower factor (mdivide_left_tri_low): the one-launch wavefront solve (k_trsv_wave);
+// the block factors and the inverses of the 128 x 128 diagonal blocks are packed from L itself.
 extern "C" int gpmi_trsv_lower(gpmi_ctx *c, const double *L, int n, int ldl, const double *b, double *z)
 {
     ENTER(c);
@@ -730,20 +730,21 @@ extern "C" int gpmi_trsv_lower(gpmi_ctx *c, const double *L, int n, int ldl, con
     const int ldd = ((n + 15) / 16) * 16 + 16;
     const int npan = (n + GPMI_NB - 1) / GPMI_NB;
     double *dL, *db, *dx, *Fall;
+    const size_t dinv = (size_t)npan * GPMI_NB * GPMI_NB;  // inverse diagonal blocks + the same of scratch, behind the factors
     if ((rc = stage_buf(c, 2, (size_t)ldd * (n + 1) * sizeof(double), &dL))) return rc;
     if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &db))) return rc;
-    if ((rc = stage_buf(c, 1, (size_t)2 * (n + 1) * sizeof(double), &dx))) return rc;
-    if ((rc = scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &Fall))) return rc;
+    if ((rc = stage_buf(c, 1, (size_t)n * sizeof(double), &dx))) return rc;
+    if ((rc = scratch_buf(c, ((size_t)npan * GPMI_FPACK + 2 * dinv) * sizeof(double), &Fall))) return rc;
+    double *Dinv = Fall + (size_t)npan * GPMI_FPACK;
     hipStream_t s = c->stream;
     HIPCHK(hipMemcpy2DAsync(dL, (size_t)ldd * sizeof(double), L, (size_t)ldl * sizeof(double),
                             (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(db, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_set_row(s, dx, 2, 0, db, n, n);  // 1 x n row vector stored with ld = 2 (16-B aligned columns)
     launch_pack_factors(s, dL, (size_t)ldd, n, Fall);
-    if ((rc = launch_trsm_right(c, dL, (size_t)ldd, n, dx, 2, 1, Fall))) return rc;
-    launch_get_row(s, dx, 2, 0, 0, n, 1.0, db);
+    launch_diag_inverses(s, Fall, n, Dinv, Dinv + dinv);
+    if ((rc = launch_trsv_lower(s, dL, (size_t)ldd, n, db, dx, Dinv))) return rc;  // one launch, the factor read once
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(z, db, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(z, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
@@ -1768,7 +1769,7 @@ struct gpmi_seq {
     SeParams p;
     double jitter;
     size_t ldm;
-    double *dX, *L, *Fall, *B, *a, *Kx, *Xs, *Ls, *u, *part, *ks, *w, *res, *kcol, *row2;
+    double *dX, *L, *Fall, *Dinv, *B, *a, *Kx, *Xs, *Ls, *u, *part, *ks, *w, *res, *kcol, *row2;
     int nchunk;
 };
 
@@ -1927,6 +1928,7 @@ extern "C" int gpmi_seq_destroy(gpmi_seq *q)
         hipFree(q->dX);
         hipFree(q->L);
         hipFree(q->Fall);
+        hipFree(q->Dinv);
         hipFree(q->B);
         hipFree(q->Kx);
         hipFree(q->Ls);
@@ -1969,6 +1971,7 @@ extern "C" int gpmi_seq_create(gpmi_ctx *c, gpmi_seq **out, const double *X, int
     SEQ_ALLOC(q->dX, (size_t)n * D + ms * D)
     SEQ_ALLOC(q->L, ldm * (size_t)(n + 1) + 4096)
     SEQ_ALLOC(q->Fall, (size_t)npan * GPMI_FPACK)
+    SEQ_ALLOC(q->Dinv, (size_t)npan * GPMI_NB * GPMI_NB)
     SEQ_ALLOC(q->B, ldm * (size_t)(n + 1) + 4096)
     SEQ_ALLOC(q->Kx, (size_t)n * ms)
     SEQ_ALLOC(q->Ls, ms * ms)
@@ -2013,16 +2016,15 @@ extern "C" int gpmi_seq_create(gpmi_ctx *c, gpmi_seq **out, const double *X, int
     launch_se_cov(c, s, q->dX, n, n, nullptr, n, n, p, jitter, 1, c->W, ld);
     SEQ_TRY(launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, q->Fall))
     launch_copy_matrix(s, c->W, ld, q->L, ldm, n, n, 1);
+    launch_diag_inverses(s, q->Fall, n, q->Dinv, U);  // for the one-launch solves below and in every step
     // G^T = L^-1 Kn^T L^-T: (Kn L^-T), transposed, times L^-T again;  B = I - (G + G^T) / 2 (:76-77)
     SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, dKn, ldm, n, q->Fall))
     launch_transpose(s, dKn, ldm, U, ldm, n, n);
     SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, U, ldm, n, q->Fall))
     launch_transpose(s, U, ldm, dKn, ldm, n, n);
     hipLaunchKernelGGL(k_seq_b, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, dKn, ldm, q->B, n);
-    // b = L^-1 mn (:56) as a one-row right-solve
-    launch_set_row(s, q->row2, 2, 0, q->u, n, n);
-    SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, q->row2, 2, 1, q->Fall))
-    launch_get_row(s, q->row2, 2, 0, 0, n, 1.0, q->a);
+    // b = L^-1 mn (:56)
+    SEQ_TRY(launch_trsv_lower(s, q->L, ldm, n, q->u, q->a, q->Dinv))
     if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "sampler set-up launch");
     int info = 0;
     if ((e = hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess)
@@ -2052,9 +2054,7 @@ extern "C" int gpmi_seq_step(gpmi_seq *q, const double *xs, double *out2)
     double *ti = q->Kx + (size_t)i * n;
     int rc;
     launch_se_cov(c, s, q->dX, n, n, q->Xs + i, 1, ms, q->p, 0.0, 0, q->kcol, (size_t)n);  // K_XsX row (:71)
-    launch_set_row(s, q->row2, 2, 0, q->kcol, n, n);
-    if ((rc = launch_trsm_right(c, q->L, q->ldm, n, q->row2, 2, 1, q->Fall))) return rc;  // t_i = L^-1 k_i
-    launch_get_row(s, q->row2, 2, 0, 0, n, 1.0, ti);
+    if ((rc = launch_trsv_lower(s, q->L, q->ldm, n, q->kcol, ti, q->Dinv))) return rc;    // t_i = L^-1 k_i, one launch
     seq_mv(q, s, q->B, q->ldm, ti, 1.0, q->u);
     hipLaunchKernelGGL(k_seq_dots, dim3(i + 2), 256, 0, s, q->Kx, n, i, q->u, q->a, q->Xs, ms, q->p, q->jitter, q->ks);
     hipLaunchKernelGGL(k_seq_cond, dim3(1), 256, (size_t)(i + 1) * sizeof(double), s, q->Ls, ms, i, q->ks, ms, q->w,

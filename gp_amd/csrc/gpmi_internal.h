@@ -141,6 +141,10 @@ void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t ld
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus);
 void launch_syrk_uut(const gpmi_ctx *c, hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n);
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all);
+// inverses of L's 128 x 128 diagonal blocks (ceil(n / 128) x 128 x 128 doubles, tmp the same) from packed factors
+void launch_diag_inverses(hipStream_t s, const double *Fpack_all, int n, double *Dinv, double *tmp);
+// t = L^-1 k for ONE right-hand side in one launch (k_trsv_wave); k and t are different buffers of n doubles
+int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *k, double *t, const double *Dinv);
 void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0, int m, double scale, double *out);
 void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
                            const int *d_info, double *d_out3, int *d_info_out, double *part /* 2 ceil(n/256) doubles */);

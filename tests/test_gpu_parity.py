@@ -186,6 +186,25 @@ def test_trmv_trsv(ctx, orc):
         np.testing.assert_allclose(ctx.trsv_lower(L, b), orc.trsv_lower(L, b), rtol=1e-10, atol=1e-12)
 
 
+def test_trsv_wavefront_many_blocks(ctx):
+    """The one-launch forward substitution (k_trsv_wave: workgroup w waits for the unknowns of the block-rows
+    above it) over 8 ... 32 block-rows, ragged last block included, against LAPACK's dtrtrs; a NaN in the
+    right-hand side propagates (and must not be mistaken for the kernel's "not yet published" bit pattern)."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(11)
+    for n in (1000, 2049, 4096):
+        G = rng.standard_normal((n, n)) / np.sqrt(n)
+        L = np.linalg.cholesky(G @ G.T + np.eye(n)); b = rng.standard_normal(n)
+        want = sla.solve_triangular(L, b, lower=True)
+        got = ctx.trsv_lower(L, b)
+        err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+        print("trsv n=%d: max rel err %.2e" % (n, err))
+        assert err <= 1e-12
+    b[700] = np.nan
+    got = ctx.trsv_lower(L, b)
+    assert np.all(np.isfinite(got[:700])) and np.all(np.isnan(got[700:]))
+
+
 def test_logml_known_answers(ctx, golden):
     for k in golden["kat"]["kats"]:
         x = np.array(k["x"]); y = np.array(k["y"])

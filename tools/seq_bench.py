@@ -1,9 +1,8 @@
-import os
 """Sequential sampler (gpmi_seq_*): set-up and per-step wall time, and the error of the
 R/tests.R:78 scenario against the oracle."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPMI_USE_PROBES", "1")  # tools run on the probe build (libgpmi_probes.so)
 import gp_amd
 from gp_amd import synth, ode_gp
