@@ -259,3 +259,20 @@ def test_sample_derivs_fused_and_batched(ctx, orc, golden):
     Pbad = P.copy(); Pbad[2, 2] = 0.0; Pbad[2, 0] = 500.0     # sy = 0, huge length-scale: K is numerically singular
     _, _, info = ctx.sample_derivs_batch(t, tis, Y, Pbad, 0.0, Z)
     assert info[2] != 0 and np.all(np.delete(info, 2) != -1)
+
+
+@pytest.mark.parametrize("n", [3583, 3585, 4609, 8193])
+def test_adaptive_outer_blocks_at_their_thresholds_vs_lapack(ctx, orc, n):
+    """The auto outer-block width follows the order of the matrix still to update (1024 / 512 / 256 / 128 columns,
+    switching at 8192 / 4608 / 3584): ragged orders right at the switches, every width in one factorisation
+    (n = 8193: 1024 -> 512 -> 256 -> 128), single-round trailing updates carrying the next diagonal block -- against
+    LAPACK, 1e-10 relative on logml."""
+    import scipy.linalg as sla
+    X, y = orc.synth(n, 3, seed=n)
+    K = orc.cov_exp_quad(X, 1.0, 0.3) + 0.01 * np.eye(n)
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+    want = -0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * n * math.log(2 * math.pi)
+    got = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
+    print("n=%d: rel err vs LAPACK %.2e" % (n, abs(got - want) / abs(want)))
+    assert abs(got - want) <= 1e-10 * abs(want)
