@@ -1044,6 +1044,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         const int gx = (M + GT - 1) / GT;
         ti = (b - (SUBWG - 1)) % gx;
         tj = (b - (SUBWG - 1)) / gx;
+    } else if (MODE == 2 && (order & 0x400)) {
+        // C = A B^T for a LOWER-triangular A (M x K, A[i][k] = 0 for k > i) and an UPPER-triangular B (N x K stored
+        // with the n index contiguous, B[j][k] = 0 for k < j -- the transpose of a lower-triangular factor): the
+        // product is lower triangular, only the tiles ti >= tj are computed (1-D grid, row-major lower triangle) and
+        // tile (ti, tj) needs the columns [128 tj, 128 (ti + 1)) only -- a sixth of the full product's work
+        if (!syrk_tile(blockIdx.x, (M + GT - 1) / GT, (M + GT - 1) / GT, 0, ti, tj)) return;
+        const int k0 = tj * GT, k1 = (ti + 1) * GT < K ? (ti + 1) * GT : K;
+        A += (size_t)k0 * lda;
+        B += (size_t)k0 * ldb;
+        K = k1 - k0;
     } else {
         ti = blockIdx.x;
         tj = blockIdx.y;
@@ -1753,6 +1763,16 @@ void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t ld
         hipLaunchKernelGGL(k_gemm_nt<2>, grid, 256, 0, s, A, lda, B, ldb, C, ldc, M, N, K, 0, 0, FuseDiag{}, KSplit{});
 }
 
+// C (n x n, lower tiles only; the caller zeroes the rest) = A B^T, A lower triangular, B the transpose of a lower
+// triangular matrix: n^3 / 3 flops instead of 2 n^3
+void launch_gemm_tri_lower(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb, double *C, size_t ldc, int n)
+{
+    if (n <= 0) return;
+    const int T = (n + GT - 1) / GT;
+    hipLaunchKernelGGL(k_gemm_nt<2>, dim3(syrk_grid(T, T, 0)), 256, 0, s, A, lda, B, ldb, C, ldc, n, n, n, 0x400, 0, FuseDiag{},
+                       KSplit{});
+}
+
 // the next panel's diagonal block is factored inside the update that completes it -- bit 0: in-block
 // GEMMs, bit 1: the trailing SYRK (multi-round launches only).  Measured with 4 grid lanes (N = 16384 /
 // 8192, ms per evaluation): off 25.0 / 4.12, GEMMs only 25.25 / 4.12, SYRK only 24.95 / 4.07, both
@@ -2106,24 +2126,28 @@ static void trsm_right_rec(const gpmi_ctx *c, hipStream_t s, const double *L, si
                            const double *Fpack_all, int upper_tri, int c0, int c1)
 {
     const int NB = GPMI_NB;
+    const bool lower_out = upper_tri == 2;  // only the rows >= a column block's first column are wanted (and kept valid)
     if (c1 - c0 <= NB) {
-        const int mr = (upper_tri && c1 < mrows) ? c1 : mrows;
-        hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)c0 * ldx, ldx, 0, mr, c1 - c0,
-                           Fpack_all + (size_t)(c0 / NB) * GPMI_FPACK);
+        const int mr = (upper_tri == 1 && c1 < mrows) ? c1 : mrows;
+        const int r0 = lower_out ? c0 : 0;
+        if (r0 < mr)
+            hipLaunchKernelGGL(k_trsm_panel, dim3((mr - r0 + 63) / 64), 256, 0, s, X + (size_t)c0 * ldx, ldx, r0, mr, c1 - c0,
+                               Fpack_all + (size_t)(c0 / NB) * GPMI_FPACK);
         return;
     }
     const int npan = (c1 - c0 + NB - 1) / NB;
     const int cm = c0 + ((npan + 1) / 2) * NB;
     trsm_right_rec(c, s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, c0, cm);
-    const int mr = (upper_tri && cm < mrows) ? cm : mrows;  // rows where X[:, c0:cm] is non-zero
-    const double *A = X + (size_t)c0 * ldx, *B = L + (size_t)cm + (size_t)c0 * ldl;
-    double *C = X + (size_t)cm * ldx;
-    if (upper_tri && (c->tune.gemm_variant == 3 || c->tune.gemm_variant == 0)) {
+    const int mr = (upper_tri == 1 && cm < mrows) ? cm : mrows;  // rows where X[:, c0:cm] is non-zero
+    const int r0 = lower_out ? cm : 0;                           // rows of the right half that are wanted
+    const double *A = X + (size_t)r0 + (size_t)c0 * ldx, *B = L + (size_t)cm + (size_t)c0 * ldl;
+    double *C = X + (size_t)r0 + (size_t)cm * ldx;
+    if (upper_tri == 1 && (c->tune.gemm_variant == 3 || c->tune.gemm_variant == 0)) {
         dim3 grid((c1 - cm + GT - 1) / GT, (mr + GT - 1) / GT);  // x: column tiles, y: row tiles (long K first)
         hipLaunchKernelGGL(k_gemm_nt<0>, grid, 256, 0, s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 0x100, 0,
                            FuseDiag{nullptr, nullptr, c0, 0, nullptr}, KSplit{});
-    } else {
-        launch_gemm_nt(c, s, A, ldx, B, ldl, C, ldx, mr, c1 - cm, cm - c0, 1);
+    } else if (mr > r0) {
+        launch_gemm_nt(c, s, A, ldx, B, ldl, C, ldx, mr - r0, c1 - cm, cm - c0, 1);
     }
     trsm_right_rec(c, s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, cm, c1);
 }
@@ -2131,21 +2155,23 @@ static void trsm_right_rec(const gpmi_ctx *c, hipStream_t s, const double *L, si
 int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
                       int mrows, const double *Fpack_all, int upper_tri)
 {
-    // X <- X L^-T by block forward substitution over the 128-column panels.  upper_tri: X is
+    // X <- X L^-T by block forward substitution over the 128-column panels.  upper_tri = 1: X is
     // upper triangular on entry (e.g. the identity) and stays so -- panel k then only has rows
-    // [0, k + kb), which cuts the work to a third.
+    // [0, k + kb), which cuts the work to a third.  upper_tri = 2: only the LOWER triangle of the result is
+    // wanted (rows >= the column's block start; the rest of X is left half-updated): the rows of a column block
+    // need, from the blocks to their left, those same rows only -- also a third of the work.
     hipStream_t s = c->stream;
     const int NB = GPMI_NB;
     // many right-hand rows: products with large K.  For a triangular X the recursion pays from
     // N ~ 12k on (value + gradient at N = 16384: 88.9 -> 83.2 ms; N = 8192: 16.0 vs 16.5 ms, N = 4096:
     // 4.5 vs 5.2 ms -- unequal tile lengths and more launches)
-    if (mrows >= 2 * GT && n > NB && (!upper_tri || n >= 12288)) {
+    if (mrows >= 2 * GT && n > NB && (upper_tri != 1 || n >= 12288)) {
         trsm_right_rec(c, s, L, ldl, X, ldx, mrows, Fpack_all, upper_tri, 0, n);
     } else {  // a few rows (triangular solve of vectors): one pass over L, panel by panel
         for (int k = 0; k < n; k += NB) {
             const int kb = (n - k < NB) ? n - k : NB;
             const double *Fp = Fpack_all + (size_t)(k / NB) * GPMI_FPACK;
-            const int mr = (upper_tri && k + kb < mrows) ? k + kb : mrows;
+            const int mr = (upper_tri == 1 && k + kb < mrows) ? k + kb : mrows;  // (lower-only output: everything, it is small)
             hipLaunchKernelGGL(k_trsm_panel, dim3((mr + 63) / 64), 256, 0, s, X + (size_t)k * ldx, ldx, 0, mr, kb, Fp);
             const int r0 = k + kb;
             if (r0 < n)

@@ -135,7 +135,9 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
 // X <- X * L^-T for the rows [row0, M) of columns [0, n) using packed factors saved by a
 // previous launch_potrf_partial(..., Fpack_all)
 int launch_trsm_right(gpmi_ctx *c, const double *L, size_t ldl, int n, double *X, size_t ldx,
-                      int mrows, const double *Fpack_all, int upper_tri = 0);
+                      int mrows, const double *Fpack_all, int upper_tri = 0 /* 1: X upper triangular, 2: lower triangle of the result only */);
+// C (lower tiles only) = A B^T for lower-triangular A and B the transpose of a lower-triangular matrix (n^3 / 3 flops)
+void launch_gemm_tri_lower(hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb, double *C, size_t ldc, int n);
 // C (M x N) = beta_is_one ? C - A B^T : A B^T   (A: M x K, B: N x K, column-major)
 void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus);
