@@ -1762,7 +1762,7 @@ extern "C" int gpmi_sample_derivs_batch(gpmi_ctx *c, const double *t, int n, con
 // call.  Here everything is expressed through the Cholesky factor K~ = L L^T and whitened kernel
 // rows t_i = L^-1 k(X, xs_i) (norm <= alpha: no cancellation of 1/jitter-sized numbers, unlike an
 // explicit K~^-1, which loses cond(K~) * eps * |K~^-1| -- 1e-5 in the R/tests.R:78 scenario):
-//   once, on the device:  B = I - sym(L^-1 Kn L^-T)  (two N-row panel solves),  b = L^-1 mn;
+//   once, on the device:  B = I - L^-1 Kn L^-T  (an N-row panel solve and one for the lower triangle alone),  b = L^-1 mn;
 //   per call:  t_i (one one-row panel solve, reads the factor once), u = B t_i (HBM-bound
 //   mat-vec), K[i,j] = k(xs_i, xs_j) - t_j . u,  m_i = t_i . b  (i + 2 dot products), and one row
 //   appended to the Cholesky factor of the star covariance: with K[g,g] = Ls Ls^T and
@@ -1781,7 +1781,8 @@ struct gpmi_seq {
 namespace {
 constexpr int MV_ROWS = 256, MV_COLS = 512;
 
-// B = I - (G + Gt) / 2 from G and its transposed copy (both read along columns)
+// B = I - G for a symmetric G of which only the LOWER triangle was computed: from G (lower valid) and its
+// transposed copy Gt (upper valid), both read along columns; B is symmetric by construction
 __global__ __launch_bounds__(256) void k_seq_b(const double *__restrict__ G, const double *__restrict__ Gt, size_t ld,
                                                double *__restrict__ Bm, int n)
 {
@@ -1793,7 +1794,7 @@ __global__ __launch_bounds__(256) void k_seq_b(const double *__restrict__ G, con
         const int c = c0 + q;
         if (c < n) {
             const size_t o = (size_t)r + (size_t)c * ld;
-            Bm[o] = (r == c ? 1.0 : 0.0) - 0.5 * (G[o] + Gt[o]);
+            Bm[o] = (r == c ? 1.0 : 0.0) - (r >= c ? G[o] : Gt[o]);
         }
     }
 }
@@ -2022,10 +2023,11 @@ extern "C" int gpmi_seq_create(gpmi_ctx *c, gpmi_seq **out, const double *X, int
     SEQ_TRY(launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, q->Fall))
     launch_copy_matrix(s, c->W, ld, q->L, ldm, n, n, 1);
     launch_diag_inverses(s, q->Fall, n, q->Dinv, U);  // for the one-launch solves below and in every step
-    // G^T = L^-1 Kn^T L^-T: (Kn L^-T), transposed, times L^-T again;  B = I - (G + G^T) / 2 (:76-77)
+    // G = L^-1 Kn L^-T: (Kn L^-T), transposed, times L^-T again -- G is symmetric (the reference symmetrises it,
+    // :76-77), so the second solve computes its lower triangle only (a third of the work) and B = I - G mirrors it
     SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, dKn, ldm, n, q->Fall))
     launch_transpose(s, dKn, ldm, U, ldm, n, n);
-    SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, U, ldm, n, q->Fall))
+    SEQ_TRY(launch_trsm_right(c, q->L, ldm, n, U, ldm, n, q->Fall, 2))
     launch_transpose(s, U, ldm, dKn, ldm, n, n);
     hipLaunchKernelGGL(k_seq_b, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, dKn, ldm, q->B, n);
     // b = L^-1 mn (:56)
