@@ -82,6 +82,23 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
 
 
+def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
+    # tools/, r/ and the launcher part of bench.py never import, link or execute oracle/; bench.py does so only inside
+    # its cpu_baseline / cpu_lapack legs (function-local imports), __graft_entry__ only in smoke() and build()
+    import re
+    for d in ("tools", "r"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".c", ".R", ".hip")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"(from|import)\s+oracle|oracle/|liboracle|libgporacle", txt), os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)from oracle import", bench, flags=re.M):
+        assert len(m.group(1)) >= 4, "bench.py imports the oracle at module level"
+    body = bench[bench.index("def main()"):]
+    assert "from oracle" not in body and "orc." not in body.split("def main()")[1].split("cpu_baseline(")[0]
+
+
 def test_null_context_is_an_error_not_a_crash():
     from gp_amd import _lib
     h = _lib.load()

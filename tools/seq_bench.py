@@ -1,5 +1,5 @@
 """Sequential sampler (gpmi_seq_*): set-up and per-step wall time.  (Parity of the R/tests.R:78 scenario against the
-oracle is a test: tests/test_gpu_seq.py::test_seq_sampler_reference_scenario -- tools never touch oracle/.)"""
+CPU restatement is a test: tests/test_gpu_seq.py::test_seq_sampler_reference_scenario.)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
