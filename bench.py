@@ -303,8 +303,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    from gp_amd.grid import logml_grid_local_dev, logml_grid_sharded_dev
+    full4 = None
+
+    def c4_step():
+        """One step of the c4 workload = the whole 64-point grid through the PRODUCT's sharded entry point
+        (gp_amd.grid.logml_grid_sharded_dev: point g -> rank g mod P on the lanes, results packed on the
+        device, ONE all_gather), on the current stream."""
+        R, S = c4_grid()
+        return logml_grid_sharded_dev(ctx, dX.data_ptr(), n, n, D, dy.data_ptr(), np.ones(C4_G), R, S, 0.0,
+                                      device=dev, comm_device=cdev)
+
     with torch.cuda.stream(stream):
-        if warm:
+        if args.workload == "c4":
+            for _ in range(max(warm, 1) if distributed else warm):  # also creates the gather's buffers / channels
+                c4_step()
+        elif warm:
             run_points(0, warm * per_step)
             if distributed:  # the gather's buffers / channels exist before the timed region, like the workspaces
                 send = dout.to(cdev)
@@ -312,13 +326,17 @@ def main():
                 dist.all_gather(gathered, send)
         barrier()
         t0 = time.perf_counter()
-        run_points(warm * per_step, (warm + steps) * per_step)  # exactly `steps` steps
-        if distributed:
-            # the path's only collective: gather the per-point results (3 doubles per point); same
-            # stream as the evaluations, so it reads them only after the lanes have joined
-            send = dout.to(cdev)
-            gathered = [torch.empty_like(send) for _ in range(world)]
-            dist.all_gather(gathered, send)
+        if args.workload == "c4":
+            for _ in range(steps):  # exactly `steps` steps, each the whole grid + its gather
+                full4 = c4_step()
+        else:
+            run_points(warm * per_step, (warm + steps) * per_step)  # exactly `steps` steps
+            if distributed:
+                # the path's only collective: gather the per-point results (3 doubles per point); same
+                # stream as the evaluations, so it reads them only after the lanes have joined
+                send = dout.to(cdev)
+                gathered = [torch.empty_like(send) for _ in range(world)]
+                dist.all_gather(gathered, send)
         barrier()
         elapsed = time.perf_counter() - t0
 
@@ -361,8 +379,12 @@ def main():
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    res = dout.cpu().numpy()
-    info = dinfo.cpu().numpy()
+    if args.workload == "c4":
+        f4 = full4.cpu().numpy()
+        res, info = f4[:, :3], f4[:, 3].astype(np.int32)
+    else:
+        res = dout.cpu().numpy()[warm * per_step:]
+        info = dinfo.cpu().numpy()[warm * per_step:]
     ok = bool(np.all(info == 0) and np.all(np.isfinite(res[:, 0])))
 
     # ---- c4 sub-record: the 64-point grid at N=8192 over the same ranks (strong scaling) --------------
@@ -372,41 +394,30 @@ def main():
         dX4 = torch.from_numpy(np.ascontiguousarray(X4.T)).to(dev)
         dy4 = torch.from_numpy(y4).to(dev)
         R4, S4 = c4_grid()
-        mine = np.arange(rank, C4_G, world)
-        per = (C4_G + world - 1) // world
-        loc = torch.full((per, 3), float("nan"), dtype=torch.float64, device=dev)
-        linfo = torch.zeros(per, dtype=torch.int32, device=dev)
-        full = torch.zeros((C4_G, 3), dtype=torch.float64, device=dev)
-        finfo = torch.zeros(C4_G, dtype=torch.int32, device=dev)
 
-        def grid_points(idx, o, i):
-            ctx.logml_grid_dev(dX4.data_ptr(), C4_N, C4_N, C4_D, dy4.data_ptr(), np.ones(idx.size), R4[idx], S4[idx], 0.0,
-                               o.data_ptr(), i.data_ptr())
+        def sharded():   # the PRODUCT's multi-GPU function: gp_amd.grid.logml_grid_sharded_dev
+            return logml_grid_sharded_dev(ctx, dX4.data_ptr(), C4_N, C4_N, C4_D, dy4.data_ptr(), np.ones(C4_G), R4, S4, 0.0,
+                                          device=dev, comm_device=cdev)
+
+        def one_rank():  # all 64 points on this rank's GPU alone, same building block, no collective
+            return logml_grid_local_dev(ctx, dX4.data_ptr(), C4_N, C4_N, C4_D, dy4.data_ptr(), np.ones(C4_G), R4, S4, 0.0, dev)
 
         with torch.cuda.stream(stream):
-            grid_points(mine, loc, linfo)  # warm-up (evaluation and the gather's buffers / channels)
-            if distributed:
-                send = loc.to(cdev)
-                parts = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(parts, send)
+            sharded()  # warm-up (evaluation and the gather's buffers / channels)
             barrier()
             t0 = time.perf_counter()
-            grid_points(mine, loc, linfo)
-            if distributed:
-                send = loc.to(cdev)
-                parts = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(parts, send)
+            got4 = sharded()
             barrier()
             tN = time.perf_counter() - t0
             # the same run's ONE-rank figure: rank 0 evaluates all 64 points, the others wait
             t1r = tN
+            ref4 = got4
             if distributed:
                 if rank == 0:
-                    allp = np.arange(C4_G)
-                    grid_points(allp, full, finfo)
+                    one_rank()
                     torch.cuda.synchronize(dev)
                     t0 = time.perf_counter()
-                    grid_points(allp, full, finfo)
+                    ref4 = one_rank()
                     torch.cuda.synchronize(dev)
                     t1r = time.perf_counter() - t0
                 barrier()
@@ -415,22 +426,14 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         tN = float(tt.item())
         if rank == 0:
-            if distributed:
-                got = np.full((C4_G, 3), np.nan)
-                recv = torch.stack(parts).cpu().numpy()
-                for r in range(world):
-                    idx = np.arange(r, C4_G, world)
-                    got[idx] = recv[r, : idx.size]
-                ref4 = full.cpu().numpy()
-                same = bool(np.array_equal(got, ref4))
-            else:
-                got = loc.cpu().numpy()
-                same = True
+            got = got4.cpu().numpy()[:, :3]
+            same = bool(np.array_equal(got, ref4.cpu().numpy()[:, :3]))
             c4 = {"workload": "c4: 64-point (rho x sigma) grid at N=%d, D=%d, point g -> rank g mod %d, one all_gather"
                               % (C4_N, C4_D, world),
                   "grid_points": C4_G, "n_gpus": world, "wall_s": tN, "evals_per_s": C4_G / tN,
                   "wall_s_one_rank_same_run": t1r, "speedup_vs_one_rank": t1r / tN,
                   "sharded_results_bit_identical_to_one_rank": same,
+                  "entry_point": "gp_amd.grid.logml_grid_sharded_dev",
                   "results_ok": bool(np.all(np.isfinite(got[:, 0]))),
                   "argmax_point": int(np.nanargmax(got[:, 0])), "logml_max": float(np.nanmax(got[:, 0]))}
 
@@ -470,7 +473,12 @@ def main():
                       "whole grid" % (n, D),
                 "c5": "c5: derivative joint [y, y'] covariance, N=%d (matrix order %d), build + fp64 Cholesky "
                       "+ solve + log-det, 1 (l, sigma) point per step per GPU" % (n, 2 * n)}[args.workload],
-                       "N": n, "D": D, "alpha": 1.0, "rho": 0.3, "sigma": 0.1,
+                       "N": n, "D": D, "alpha": 1.0,
+                       "rho": {"c3": "0.300 ... 0.345: step k of rank r evaluates rho = 0.3 (1 + 0.01 ((k P + r) mod 16)) "
+                                     "(distinct points, as a grid or a sampler would ask for)",
+                               "c4": "8 log-spaced values in [0.1, 1.0] (x 8 sigma values)",
+                               "c5": "l = 0.500 ... 0.535: step k evaluates l = 0.5 (1 + 0.01 (k mod 8))"}[args.workload],
+                       "sigma": "8 log-spaced values in [0.05, 0.5]" if args.workload == "c4" else 0.1,
                        "nb_outer": args.nb_outer or "auto(adaptive: %d for the first block, narrower as the trailing matrix shrinks)" % nbo_auto,
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
@@ -479,7 +487,7 @@ def main():
             "grid_lanes": args.grid_lanes or "auto(4)",
             "ms_per_eval_sequential": seq_ms,
             "ms_per_eval_sequential_instrumented": seq_inst_ms,
-            "logml_first": float(res[warm * per_step, 0]),
+            "logml_first": float(res[0, 0]),
             "cholesky_tflops_per_gpu_whole_eval": chol_flops * evals / world / elapsed / 1e12,
             "roofline": {
                 "kernel": "k_gemm_nt<1> (trailing-update SYRK, v_mfma_f64_16x16x4_f64)",

@@ -109,6 +109,68 @@ def test_c3_n8192_vs_lapack(ctx, orc):
     assert abs(got[0] - lap) <= LOGML_RTOL * abs(lap)
 
 
+def _lapack_logml_inplace(K, y):
+    """LAPACK dpotrf / dtrtrs (scipy, OpenBLAS, all host threads of the box's share) on a Fortran-order K,
+    factored in place (no second 2.1 GB copy at order 16384).  Returns logml, sum log L_ii, z'z."""
+    import scipy.linalg as sla
+    n = len(y)
+    assert K.flags.f_contiguous
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+    sld = float(np.log(np.diag(L)).sum())
+    q = float(z @ z)
+    return -0.5 * q - sld - 0.5 * n * math.log(2 * math.pi), sld, q
+
+
+def test_c3_n16384_vs_lapack(ctx, orc):
+    """BASELINE.json's metric configuration itself (c3: N = 16384, D = 3, alpha = 1, rho = 0.3, sigma = 0.1;
+    models/fit_hyperparameters.stan:18-32) against an INDEPENDENT value: the oracle's cov_exp_quad on the
+    host, LAPACK dpotrf + dtrtrs in place (about a minute on the box's host cores).  Gate: the north-star
+    1e-8 relative on logml; the two halves (log-determinant, quadratic form) are gated and printed
+    separately.  Device-resident and host-buffer entry points must agree bit for bit."""
+    import time
+    n, D = 16384, 3
+    X, y, dX, dy = _dev_inputs(n, D)
+    got = ctx.logml(X, y, 1.0, [0.3], 0.1)
+    t0 = time.perf_counter()
+    K = orc.cov_exp_quad(X, 1.0, 0.3)
+    K[np.diag_indices(n)] += 0.1 * 0.1
+    t1 = time.perf_counter()
+    lm, sld, q = _lapack_logml_inplace(K, y)
+    t2 = time.perf_counter()
+    del K
+    e_lm, e_sld, e_q = abs(got[0] - lm) / abs(lm), abs(got[1] - sld) / abs(sld), abs(got[2] - q) / abs(q)
+    print("c3 N=16384: logml gpu %.12e lapack %.12e rel %.2e; sum log diag rel %.2e; quad form rel %.2e "
+          "(host: build %.1f s, dpotrf+dtrtrs %.1f s)" % (got[0], lm, e_lm, e_sld, e_q, t1 - t0, t2 - t1))
+    assert e_lm <= LOGML_RTOL and e_sld <= LOGML_RTOL and e_q <= LOGML_RTOL, (e_lm, e_sld, e_q)
+    import torch
+    out = torch.zeros(3, dtype=torch.float64, device=dX.device)
+    info = torch.zeros(1, dtype=torch.int32, device=dX.device)
+    ctx.logml_dev(dX.data_ptr(), n, n, D, dy.data_ptr(), 1.0, [0.3], 0.1, 0.0, out.data_ptr(), info.data_ptr())
+    ctx.sync()
+    assert int(info.item()) == 0 and out.cpu().numpy()[0] == got[0]
+
+
+def test_c5_joint_order16384_vs_lapack(ctx, orc):
+    """Config c5 at ITS size: the joint [y, y'] covariance [[QQ + s^2 I, QR], [RQ, RR]] + 1e-6 I
+    (R/ode_gp_library.R:29-30) of N = 8192 points, matrix order 16384, l = 0.5, sigma = 0.1, against the
+    oracle's joint matrix factored by LAPACK in place.  Gate 1e-8 on logml and on both halves."""
+    import time
+    n = 8192
+    t = np.linspace(0, 10, n); yy = np.concatenate([np.sin(t), np.cos(t)])
+    got = ctx.joint_logml(t, yy, 1.0, 0.5, 0.1, 1e-6)
+    t0 = time.perf_counter()
+    K = orc.joint_cov(t, 1.0, 0.5, 0.1, 1e-6)
+    t1 = time.perf_counter()
+    lm, sld, q = _lapack_logml_inplace(K, yy)
+    t2 = time.perf_counter()
+    del K
+    e_lm, e_sld, e_q = abs(got[0] - lm) / abs(lm), abs(got[1] - sld) / abs(sld), abs(got[2] - q) / abs(q)
+    print("c5 order 16384: logml gpu %.12e lapack %.12e rel %.2e; sum log diag rel %.2e; quad form rel %.2e "
+          "(host: build %.1f s, dpotrf+dtrtrs %.1f s)" % (got[0], lm, e_lm, e_sld, e_q, t1 - t0, t2 - t1))
+    assert e_lm <= LOGML_RTOL and e_sld <= LOGML_RTOL and e_q <= LOGML_RTOL, (e_lm, e_sld, e_q)
+
+
 def test_c4_grid_n8192_subset(ctx):
     # config c4 (64-point rho x sigma grid at N=8192): a 2 x 2 corner of the grid through the grid
     # entry point equals single evaluations bit for bit; values order sensibly
