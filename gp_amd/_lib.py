@@ -29,7 +29,7 @@ SYMBOLS = (
     "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_kernel_timing_ex",
 )
 # additionally exported by the probe build (libgpmi_probes.so, -DGPMI_PROBES; tools/ only)
-PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock", "gpmi_probe_fused")
+PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock", "gpmi_probe_fused", "gpmi_probe_small")
 
 
 class GpmiError(RuntimeError):
@@ -461,6 +461,12 @@ class Context:
     def probe_fused(self):
         out = np.zeros(5)
         _chk(self._probe("gpmi_probe_fused")(self._h, _p(out)))
+        return out
+
+    def probe_small(self):
+        """(build, diagonal blocks, rows below, launches, trailing tiles, finalize): cycles since the last call."""
+        out = np.zeros(6)
+        _chk(self._probe("gpmi_probe_small")(self._h, _p(out)))
         return out
 
     def probe_mfma_peak(self, iters=20000):

@@ -55,6 +55,7 @@ __device__ __host__ constexpr int fp_inv(int jb) { return 28 + jb; }
 
 
 #include "factor16.h"
+#include "se_device.h"
 
 // ---------------------------------------------------------------------------
 // Diagonal block (<= 128 x 128).  One workgroup of 5 waves:
@@ -193,18 +194,23 @@ constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 2 * 16 * 17;  // doubles of wo
 // FULL: the block has all 128 rows and columns (every panel but a ragged last one): the tiles below the
 // diagonal are loaded and stored unconditionally -- the guarded form costs a compare, an exec-mask
 // save / restore and a branch per ELEMENT (60 per lane), ~3 us per block
+// nblk (ragged blocks only): number of 16-column pivot blocks to run, ceil(nb_act / 16) -- a small matrix does not
+// pay for the identity padding's pivots (n = 21: 2 of 8 block columns); Fpack slots of the skipped blocks are then
+// never read by the consumers, which loop over the same count
 template <bool COH = false, bool FULL = false>
 __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double *__restrict__ A, size_t lda, int nb_act,
-                                                 double *__restrict__ Fpack, int *info, int col0)
+                                                 double *__restrict__ Fpack, int *info, int col0, int nblk = 8,
+                                                 int tid = (int)threadIdx.x)
 {
+    if (FULL) nblk = 8;
     double (*s_pub)[8][256] = reinterpret_cast<double (*)[8][256]>(sm);
     double (*s_inv)[256] = reinterpret_cast<double (*)[256]>(sm + 2 * 8 * 256);
     // the diagonal tile travels to the factor wave and comes back as L16 through s_d16[kb & 1]: two
     // buffers, so that the owner of block-row kb + 1 can hand over the NEXT diagonal tile while the
     // owner of block-row kb still reads L16 of this step
     double (*s_d16)[16][17] = reinterpret_cast<double (*)[16][17]>(sm + 2 * 8 * 256 + 8 * 256);
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
 
     // TWO workgroup barriers per block column.  The chain factor16(kb) -> solve of block-row kb + 1 ->
@@ -214,7 +220,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     // third barrier of the earlier form cost ~2 k of the ~7.7 k cycles per step).
     if (w == 3) {
 #pragma unroll 1
-        for (int kb = 0; kb < 8; ++kb) {
+        for (int kb = 0; kb < nblk; ++kb) {
             __syncthreads();  // B1: the owner's diagonal tile is in s_d16[kb & 1]; -X tiles of step kb - 1 published
             const int bad = factor16(s_d16[kb & 1], s_inv[kb], lane);
             if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
@@ -285,6 +291,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
+        if (!FULL && kb >= nblk) break;  // workgroup-uniform
         __syncthreads();  // B1: diagonal tile kb is in s_d16[kb & 1]; every wave's -X tiles of step kb - 1 are published
         if (kb > 0) {     // REST of step kb - 1: tiles jb >= kb of the rows below, except tile (kb, kb)
             if (ra >= kb) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
@@ -354,9 +361,9 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, 
 // stores from one running column pointer (the guarded form predicates and branches per element)
 template <bool FULL>
 __device__ __forceinline__ void trsm_panel_body(const double *__restrict__ s_F, double *__restrict__ Acol, size_t lda,
-                                                int r, bool rok, int nb_act)
+                                                int r, bool rok, int nb_act, int tid = (int)threadIdx.x)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = tid & 63;
     const int lq = lane >> 4;
     const int nblk = FULL ? 8 : (nb_act + 15) >> 4;
     d4 T[8];
@@ -1430,6 +1437,302 @@ __global__ __launch_bounds__(512, 2) void k_gemm9(const double *__restrict__ A, 
 
 #endif  // GPMI_PROBES
 
+// ---------------------------------------------------------------------------
+// Small problems: ONE workgroup does a whole evaluation.
+//
+// The reference's drivers call the path at N = 21 (R/tests.R:5-19), 79 .. 199 (pendulum_fit*.R:206-214) and
+// 256 (BASELINE c1); there the chain of launches of the blocked code (build, row, diagonal block, panel solve,
+// update, ..., two finalize kernels) is pure launch latency.  Here one workgroup of 4 waves runs the same
+// device functions back to back on a matrix that never leaves its CU's L2:
+//   build (se_cov_tile: the arithmetic of k_se_cov, bit-identical K)  ->  for every 128-column panel:
+//   potrf_diag4_body (packed factors to LDS)  ->  rows below by trsm_panel_body strips  ->  trailing tiles by
+//   gemm_tile<1> / gemm_quad64  ->  log-det and quadratic form, reduced in the order of k_logml_partial.
+// The right-hand side y rides along as row n; when it is the only row below the last panel
+// its solve is a VALU forward substitution from the packed factors in LDS (two barriers per 16 pivots) instead
+// of a 144-MFMA strip.  Phase boundaries are __syncthreads(): global memory written by one wave of a workgroup
+// is visible to the others behind the barrier (one CU, one L1).  A grid of G hyper-parameter points is G
+// workgroups of ONE launch (k_logml_small_batch), each with its own workspace slice.
+// ---------------------------------------------------------------------------
+#ifdef GPMI_PROBES  // phase stamps of the small kernels (block 0, thread 0): g_fz[0] build, [1] diagonal blocks, [2] rows below, [3] launches, [4] trailing tiles, [5] finalize
+#define GPMI_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime();
+#define GPMI_STAMP_ADD(i, d) if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_fz[i], (unsigned long long)(d));
+#else
+#define GPMI_STAMP(v)
+#define GPMI_STAMP_ADD(i, d)
+#endif
+struct SmallSe {            // hyper-parameters of one point, in registers
+    double a2;
+    double inv_ell[GPMI_MAXD];
+    int D;
+};
+
+// z = L11^-1 r for ONE right-hand row (W[row, 0 .. nb), stride ld) against the packed factors of a <= 128-order
+// block in LDS: per 16-pivot block, z_kb = Linv16[kb] r_kb by 16 threads, then every row below subtracts
+// L[r][kb] z_kb -- -L tiles and inverses in the fragment order potrf_diag4_body packs them in.
+__device__ __forceinline__ void small_row_solve(const double *__restrict__ s_F, double *__restrict__ s_r,
+                                                double *__restrict__ s_z, double *__restrict__ Wrow, size_t ld, int nb, int t)
+{
+    const int nblk = (nb + 15) >> 4;
+    if (t < 128) s_r[t] = (t < nb) ? Wrow[(size_t)t * ld] : 0.0;
+    __syncthreads();
+    // every LDS read of a step is issued before its first use (fully unrolled, two accumulators): a loop with a
+    // per-lane trip count made each of the 16 products wait for its own pair of reads (3 k cycles per step)
+    for (int kb = 0; kb < nblk; ++kb) {
+        if (t < 16) {
+            double f[16], r[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                f[c] = s_F[fp_inv(kb) * 256 + (c >> 2) * 64 + (c & 3) * 16 + t];  // Linv16[t][c], zero above the diagonal
+                r[c] = s_r[kb * 16 + c];
+            }
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) {
+                z0 = fma(f[c], r[c], z0);
+                z1 = fma(f[c + 1], r[c + 1], z1);
+            }
+            s_z[kb * 16 + t] = z0 + z1;
+        }
+        __syncthreads();
+        if (t < 128 && t >= (kb + 1) * 16 && t < nblk * 16) {
+            const int jb = t >> 4, lr = t & 15;
+            double f[16], z[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                f[c] = s_F[fp_l(jb, kb) * 256 + (c >> 2) * 64 + (c & 3) * 16 + lr];  // -L[t][16 kb + c]
+                z[c] = s_z[kb * 16 + c];
+            }
+            double a0 = s_r[t], a1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) {
+                a0 = fma(f[c], z[c], a0);
+                a1 = fma(f[c + 1], z[c + 1], a1);
+            }
+            s_r[t] = a0 + a1;
+        }
+        __syncthreads();
+    }
+    if (t < nb) Wrow[(size_t)t * ld] = s_z[t];
+}
+
+// Right-looking partial factorisation by ONE workgroup: the first nfac columns of the M x ncol lower trapezoid in
+// W are factored, rows below / the trailing block updated (launch_potrf_partial's contract).  one_row: the caller
+// promises M == ncol + 1 == nfac + 1 (one augmented row), which lets the last panel use small_row_solve.
+__device__ __forceinline__ void small_potrf_partial(double (&smem)[2][2][GK][GP], double *__restrict__ s_F,
+                                                    double *__restrict__ s_aux, double *__restrict__ W, size_t ld, int M,
+                                                    int ncol, int nfac, int *info, bool one_row)
+{
+    const size_t ld0 = ld;
+    // thread index, re-read behind an optimisation barrier in front of every phase: everything a phase derives from it
+    // (LDS addresses, lane masks, column offsets: hundreds of values) is then computed where it is used instead of
+    // being hoisted in front of the panel loop and kept in scratch memory across all phases
+    auto fresh_tid = []() {
+        int t = (int)threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    for (int k = 0; k < nfac; k += GPMI_NB) {
+        const int nb = (nfac - k < GPMI_NB) ? nfac - k : GPMI_NB;
+        // the leading dimension is made opaque per panel: otherwise every per-element offset of every phase (hundreds of
+        // 64-bit values) is hoisted out of this loop and stays live across all phases -- the kernel then needs 512
+        // registers, copies values through AGPRs around factor16's hand-scheduled DPP chain and breaks its hazard
+        // assumptions (the hazard recogniser cannot see into the asm statements)
+        size_t ld = ld0;
+        asm volatile("" : "+s"(ld));
+        double *Akk = W + (size_t)k + (size_t)k * ld;
+        GPMI_STAMP(ts0)
+        if (nb == GPMI_NB) potrf_diag4_body<false, true>(&smem[0][0][0][0], Akk, ld, nb, s_F, info, k, 8, fresh_tid());
+        else potrf_diag4_body<false, false>(&smem[0][0][0][0], Akk, ld, nb, s_F, info, k, (nb + 15) >> 4, fresh_tid());
+        __syncthreads();
+        GPMI_STAMP(ts1)
+        GPMI_STAMP_ADD(1, ts1 - ts0)
+        const int r0 = k + nb;
+        if (r0 >= M) break;
+        if (one_row && M - r0 == 1) {
+            small_row_solve(s_F, s_aux, s_aux + 128, W + (size_t)r0 + (size_t)k * ld, ld, nb, fresh_tid());
+            __syncthreads();
+            GPMI_STAMP(ts2)
+            GPMI_STAMP_ADD(2, ts2 - ts1)
+            break;
+        }
+        // rows [r0, M): 16-row strips, one per wave, 64 rows per round
+        for (int rb = r0; rb < M; rb += 64) {
+            const int tid = fresh_tid();
+            const int r = rb + (tid >> 6) * 16 + (tid & 15);
+            if (nb == GPMI_NB && rb + 64 <= M) trsm_panel_body<true>(s_F, W + (size_t)k * ld, ld, r, true, nb, tid);
+            else trsm_panel_body<false>(s_F, W + (size_t)k * ld, ld, r, r < M, nb, tid);
+        }
+        __syncthreads();
+        GPMI_STAMP(ts2)
+        GPMI_STAMP_ADD(2, ts2 - ts1)
+        // trailing block: C[r0.., r0..ncol) -= X X^T, lower tiles
+        const int mt = M - r0, nt = ncol - r0;
+        if (nt <= 0) continue;
+        const double *X = W + (size_t)r0 + (size_t)k * ld;
+        double *C = W + (size_t)r0 + (size_t)r0 * ld;
+        const int T = (mt + GT - 1) / GT, TN = (nt + GT - 1) / GT;
+        for (int ti = 0; ti < T; ++ti) {
+            const int vr = (mt - ti * GT < GT) ? mt - ti * GT : GT;  // valid rows of this tile row
+            for (int tj = 0; tj <= ti && tj < TN; ++tj) {
+                if (vr <= 64 && nb % GK == 0) {  // thin tile row (e.g. the augmented row alone): 64-row quadrants
+                    for (int qn = 0; qn < 2; ++qn) {
+                        const int m0 = ti * GT, n0 = tj * GT + qn * 64;
+                        if (n0 >= nt || (ti == tj && qn > 0)) continue;
+                        gemm_quad64(&smem[0][0][0][0], X + m0, ld, X + n0, ld, C + (size_t)m0 + (size_t)n0 * ld, ld, nb, mt - m0,
+                                    nt - n0, fresh_tid());
+                        __syncthreads();
+                    }
+                } else {
+                    gemm_tile<1>(smem, X, ld, X, ld, C, ld, mt, nt, nb, ti, tj, 0, fresh_tid());
+                    __syncthreads();
+                }
+            }
+        }
+        GPMI_STAMP(ts3)
+        GPMI_STAMP_ADD(4, ts3 - ts2)
+    }
+}
+
+// One evaluation of models/fit_hyperparameters.stan:18-32 at n <= SMALL_N_MAX by one workgroup.
+__device__ __forceinline__ void logml_small_body(double (&smem)[2][2][GK][GP], double *__restrict__ s_F, double *__restrict__ s_aux,
+                                                 const double *__restrict__ X, int n, int ldx, const double *__restrict__ y,
+                                                 const SmallSe &se, double diag_add, double *__restrict__ W, size_t ld,
+                                                 double *__restrict__ out3, int *info_out, int *info_w, const ExpC &ec)
+{
+    const int tid = threadIdx.x;
+    GPMI_STAMP(tb0)
+    if (tid == 0) *info_w = 0;
+    // covariance, lower 64 x 64 tiles, from the scaled coordinates staged ONCE in LDS (the staging buffer of the later
+    // phases is free): one global round trip instead of one per tile and operand; y^T as row n
+    {
+        double *xs = &smem[0][0][0][0];
+#pragma unroll
+        for (int d = 0; d < GPMI_MAXD; ++d)
+            if (d < se.D)
+                for (int i = tid; i < n; i += 256) xs[i + d * n] = __dmul_rn(X[(size_t)i + (size_t)d * ldx], se.inv_ell[d]);
+        __syncthreads();
+        for (int row0 = 0; row0 < n; row0 += SE_TR)
+            for (int col0 = 0; col0 < row0 + SE_TR && col0 < n; col0 += SE_TC) {
+                switch (se.D) {
+                case 1: se_cov_tile<1, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                case 2: se_cov_tile<2, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                case 3: se_cov_tile<3, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                default: se_cov_tile<0, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                }
+            }
+    }
+    for (int j = tid; j < n; j += 256) W[(size_t)n + (size_t)j * ld] = y[j];
+    __syncthreads();
+    GPMI_STAMP(tb1)
+    GPMI_STAMP_ADD(0, tb1 - tb0)
+    GPMI_STAMP_ADD(3, 1)
+    small_potrf_partial(smem, s_F, s_aux, W, ld, n + 1, n, n, info_w, true);
+    GPMI_STAMP(tb2)
+    // sum log L_ii, z'z: the reduction tree of k_logml_partial / k_logml_finalize (n <= 256: one slice)
+    double a = 0.0, b = 0.0;
+    if (tid < n) {
+        a = log(W[(size_t)tid * (ld + 1)]);
+        const double z = W[(size_t)n + (size_t)tid * ld];
+        b = z * z;
+    }
+    double *s_a = s_aux, *s_b = s_aux + 256;
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            s_a[tid] += s_a[tid + st];
+            s_b[tid] += s_b[tid + st];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int info = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (info_out) *info_out = info;
+        if (info) {
+            out3[0] = out3[1] = out3[2] = __builtin_nan("");
+        } else {
+            out3[1] = s_a[0];
+            out3[2] = s_b[0];
+            out3[0] = -0.5 * s_b[0] - s_a[0] - 0.5 * (double)n * 1.8378770664093454835606594728112;  // log(2 pi)
+        }
+    }
+    GPMI_STAMP(tb3)
+    GPMI_STAMP_ADD(5, tb3 - tb2)
+}
+
+constexpr int SMALL_PTS = 128;  // grid points per launch: their hyper-parameters travel as kernel arguments
+struct SmallBatch {
+    double a2[SMALL_PTS], inv_rho[SMALL_PTS], diag[SMALL_PTS];
+};
+
+// Workgroup memory of the small kernels: staging buffer of gemm_tile / workspace of the diagonal-block body, the
+// packed factors of the current panel, reduction / substitution scratch.  DYNAMIC: with 148 KB of static LDS the
+// compiler knows that one workgroup fits per CU, hands the kernel all 512 registers and moves values through AGPRs
+// around factor16's hand-scheduled DPP chain -- whose hazard spacing (the recogniser cannot see into asm statements)
+// it thereby breaks (v_accvgpr_read directly in front of a DPP read of the same register: wrong numbers).  With
+// the size unknown at compile time __launch_bounds__(256, 2) holds and the kernel is allocated like k_gemm_nt<0>:
+// <= 256 registers, no AGPR traffic.
+constexpr int SMALL_LDS_DOUBLES = 2 * 2 * GK * GP + GPMI_FPACK + 512;
+extern __shared__ __attribute__((aligned(16))) double small_lds[];
+#define GPMI_SMALL_LDS                                                                                   \
+    double (&smem)[2][2][GK][GP] = *reinterpret_cast<double (*)[2][2][GK][GP]>(small_lds);               \
+    double *s_F = small_lds + 2 * 2 * GK * GP;                                                           \
+    double *s_aux = s_F + GPMI_FPACK;
+
+// stage (nullable): X and y are host-mapped memory (the host-buffer entry point): they are first copied, one
+// coalesced pass with every load in flight (one PCIe round trip), to `stage` in device memory; out3 / info_out
+// may likewise be host-mapped -- nothing is copied around the launch
+__global__ __launch_bounds__(256, 2) void k_logml_small(const double *__restrict__ X, int n, int ldx, const double *__restrict__ y,
+                                                     SeParams p, double diag_add, double *__restrict__ W, size_t ld,
+                                                     double *__restrict__ out3, int *info_out, int *info_w, ExpC ec,
+                                                     double *__restrict__ stage)
+{
+    GPMI_SMALL_LDS
+    if (stage) {
+        const int nx = n * p.D;
+        for (int e = threadIdx.x; e < nx + n; e += 256) {
+            const int d = e / n, i = e - d * n;
+            stage[e] = (e < nx) ? X[(size_t)i + (size_t)d * ldx] : y[e - nx];
+        }
+        __syncthreads();
+        X = stage;
+        y = stage + nx;
+        ldx = n;
+    }
+    SmallSe se;
+    se.a2 = p.a2;
+    se.D = p.D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = p.inv_ell[d];
+    logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, diag_add, W, ld, out3, info_out, info_w, ec);
+}
+
+// workgroup g = point g of the batch: isotropic (alpha, rho, sigma) as in gpmi_logml_grid; workspace slice g
+__global__ __launch_bounds__(256, 2) void k_logml_small_batch(const double *__restrict__ X, int n, int ldx, int D,
+                                                           const double *__restrict__ y, SmallBatch b, double *__restrict__ Wall,
+                                                           size_t wstride, size_t ld, double *__restrict__ out3, int *info_out,
+                                                           int *info_w, ExpC ec)
+{
+    GPMI_SMALL_LDS
+    const int g = blockIdx.x;
+    SmallSe se;
+    se.a2 = b.a2[g];
+    se.D = D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = b.inv_rho[g];
+    logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, b.diag[g], Wall + (size_t)g * wstride, ld, out3 + 3 * (size_t)g,
+                     info_out + g, info_w + g, ec);
+}
+
+// the factorisation alone (launch_potrf_partial at small sizes: posteriors, rbf_cov_chol, ...)
+__global__ __launch_bounds__(256, 2) void k_potrf_small(double *__restrict__ W, size_t ld, int M, int ncol, int nfac, int *info)
+{
+    GPMI_SMALL_LDS
+    small_potrf_partial(smem, s_F, s_aux, W, ld, M, ncol, nfac, info, false);
+}
+#undef GPMI_SMALL_LDS
+
 // Packed factors (Fpack) of an ALREADY factored diagonal block: -L tiles in fragment
 // order and the inverse of every 16x16 diagonal tile.  Used by solves against a given L.
 __global__ __launch_bounds__(512) void k_pack_factors(const double *__restrict__ L11, size_t ldl,
@@ -1711,6 +2014,19 @@ __global__ __launch_bounds__(256) void k_probe_peak(double *sink, int iters)
 // ---------------------------------------------------------------------------
 // host-side drivers
 // ---------------------------------------------------------------------------
+// the small kernels use more dynamic workgroup memory than the default limit: raise it once per device
+static void small_lds_attr()
+{
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
+    const int bytes = SMALL_LDS_DOUBLES * (int)sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[dev] = true;
+}
+
 void gpmi_tuning_defaults(gpmi_tuning *t)
 {
     t->syrk_order = 0;
@@ -1727,6 +2043,9 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->se_nt = 1;
     t->gemm_variant = 3;
     t->rect_auto = 0;
+    t->small_n = 256;
+    t->small_n1 = 128;
+    t->small_m = 160;
 }
 
 void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
@@ -1991,6 +2310,15 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
     // trapezoid in W; the trailing [nfac, ncol) part receives the Schur complement.
     // outer block width: K of the trailing update.  Wider blocks cut the C traffic and the
     // number of epilogues once the trailing matrix is large; 256 keeps the panel phase short.
+    // small matrices: the whole partial factorisation in ONE workgroup of one launch (k_potrf_small) instead of a
+    // chain of latency-bound launches (tune.small_m; callers that keep the packed factors take the blocked path)
+    if (!Fpack_all && M <= c->tune.small_m && M > 0 && nfac > 0) {
+        small_lds_attr();
+        hipLaunchKernelGGL(k_potrf_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), c->stream, W, ld, M, ncol, nfac, d_info);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "potrf launch failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     auto nbo_for = [c](int cols) {
         return cols >= c->tune.nb_thr[0] ? 1024 : (cols >= c->tune.nb_thr[1] ? 512 : (cols >= c->tune.nb_thr[2] ? 256 : 128));
     };
@@ -2211,6 +2539,41 @@ int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const d
     return 0;
 }
 
+// ---- small-N evaluations: one workgroup each ------------------------------------------------
+// workspace slice of one n-point problem: leading dimension and stride (doubles) between consecutive slices
+void small_ws_layout(int n, size_t *ld, size_t *stride)
+{
+    *ld = (size_t)(((n + 1 + 15) / 16) * 16 + 16);
+    *stride = *ld * (size_t)(n + 1) + 256;  // tile loads may over-read rows past the end of the last column
+}
+
+void launch_logml_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
+                        double *W, size_t ld, double *d_out3, int *d_info_out, int *d_info_work, double *stage)
+{
+    small_lds_attr();
+    hipLaunchKernelGGL(k_logml_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, dy, p, diag_add, W, ld, d_out3,
+                       d_info_out, d_info_work, h_exp, stage);
+}
+
+// G <= GPMI_SMALL_PTS points (alpha, rho, sigma) in ONE launch of G workgroups; Wall: G slices (small_ws_layout)
+void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                              const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_out3,
+                              int *d_info_out, int *d_info_work)
+{
+    static_assert(SMALL_PTS == GPMI_SMALL_PTS, "batch size of the small-N grid launch");
+    SmallBatch b;
+    for (int g = 0; g < G; ++g) {
+        b.a2[g] = alpha[g] * alpha[g];
+        b.inv_rho[g] = 1.0 / rho[g];
+        b.diag[g] = sigma[g] * sigma[g] + jitter;
+    }
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_logml_small_batch, dim3(G), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall, stride, ld, d_out3, d_info_out,
+                       d_info_work, h_exp);
+}
+
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)
 {
     for (int k = 0; k < n; k += GPMI_NB) {
@@ -2251,7 +2614,7 @@ int probe_fused_read(hipStream_t s, unsigned long long *out5)
 {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
-    if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_fz), 5 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_fz), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fz), z, sizeof z) != hipSuccess;
 }
 

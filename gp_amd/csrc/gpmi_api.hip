@@ -278,6 +278,7 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         free(c->itp_lp);
         hipFree(c->d_out);
         hipFree(c->d_fin);
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
         hipFree(c->scratch);
         for (int i = 0; i < 4; ++i) {
             hipFree(c->stage[i]);
@@ -367,6 +368,21 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     if (!strcmp(name, "nb_thr1024") || !strcmp(name, "nb_thr512") || !strcmp(name, "nb_thr256")) {
         if (value < 0) return gpmi_fail(GPMI_EARG, "%s must be >= 0", name);
         c->tune.nb_thr[name[6] == '1' ? 0 : (name[6] == '5' ? 1 : 2)] = value;
+        return 0;
+    }
+    if (!strcmp(name, "small_n")) {  // one-workgroup marginal likelihood up to this n (0: off, <= 256)
+        if (value < 0 || value > 256) return gpmi_fail(GPMI_EARG, "small_n must be 0 .. 256");
+        c->tune.small_n = value;
+        return 0;
+    }
+    if (!strcmp(name, "small_n1")) {  // ... for ONE evaluation (grids of fewer than 6 points)
+        if (value < 0 || value > 256) return gpmi_fail(GPMI_EARG, "small_n1 must be 0 .. 256");
+        c->tune.small_n1 = value;
+        return 0;
+    }
+    if (!strcmp(name, "small_m")) {  // one-workgroup partial factorisation up to this many rows (0: off)
+        if (value < 0 || value > 1024) return gpmi_fail(GPMI_EARG, "small_m must be 0 .. 1024");
+        c->tune.small_m = value;
         return 0;
     }
     if (!strcmp(name, "syrk_order")) {
@@ -802,11 +818,51 @@ static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
 }
 
 // ---- marginal likelihood -----------------------------------------------------
+// n small enough for the one-workgroup evaluation (k_logml_small): the sizes the reference's own drivers run
+// at (R/tests.R:5 N = 21, pendulum_fit*.R 79 .. 199, BASELINE c1 N = 256)
+static bool small_logml(const gpmi_ctx *c, int n, int D, int G = 1)
+{
+    // one workgroup against the multi-CU launch chain (tools/small_n_bench.py, one evaluation / 64 points, us per
+    // evaluation): n = 21: 20 vs 36 / 0.6 vs 22; 128: 43 vs 43 / 1.0 vs 23; 199: 118 vs 89 / 2.2 vs 33; 256: 145 vs 79 / 2.6 vs 30
+    const int lim = (G >= 6 || c->tune.small_n1 > c->tune.small_n) ? c->tune.small_n : c->tune.small_n1;
+    return lim > 0 && n <= lim && D <= GPMI_MAXD;
+}
+
+// workspace for `count` slices of the small-N kernel
+static int reserve_ws_small(gpmi_ctx *c, int n, int count)
+{
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    const size_t need = (stride * (size_t)count + 4096) * sizeof(double);
+    if (need > c->W_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->W) HIPCHK(hipFree(c->W));
+        c->W = nullptr;
+        c->W_bytes = 0;
+        if (hipMalloc((void **)&c->W, need) != hipSuccess)
+            return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of workspace", need);
+        c->W_bytes = need;
+    }
+    c->ld = (int)ld;
+    c->ncols = n;
+    return 0;
+}
+
 static int logml_core(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dy, const SeParams &p,
                       double diag_add, double *d_out3, int *d_info)
 {
     int rc;
     const int M = n + 1;
+    if (small_logml(c, n, p.D)) {  // build, factorisation, solve and log-det in ONE launch of one workgroup
+        if ((rc = reserve_ws_small(c, n, 1))) return rc;
+        tic(c, 0);
+        tic(c, 1);
+        launch_logml_small(c->stream, dX, n, ldx, dy, p, diag_add, c->W, (size_t)c->ld, d_out3, d_info, c->d_info, nullptr);
+        tic(c, 2);
+        tic(c, 3);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if ((rc = reserve_ws(c, M, n))) return rc;
     const size_t ld = (size_t)c->ld;
     tic(c, 0);
@@ -845,6 +901,22 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
     if (G == 0) return 0;
     if (n <= 0 || !dX || !dy || !alpha || !rho || !sigma || !d_out3 || !d_info || ldx < n)
         return gpmi_fail(GPMI_EARG, "bad argument");
+    if (small_logml(c, n, D, G)) {
+        // small n: every point is ONE workgroup; up to GPMI_SMALL_PTS points per launch (their hyper-parameters
+        // travel as kernel arguments), no lanes, no per-point launch chain
+        for (int g = 0; g < G; ++g)
+            if (!(rho[g] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
+        const int per = G < GPMI_SMALL_PTS ? G : GPMI_SMALL_PTS;
+        int rc = reserve_ws_small(c, n, per);
+        if (rc) return rc;
+        for (int g0 = 0; g0 < G; g0 += GPMI_SMALL_PTS) {
+            const int gc = (G - g0 < GPMI_SMALL_PTS) ? G - g0 : GPMI_SMALL_PTS;
+            launch_logml_small_batch(c->stream, dX, n, ldx, D, dy, alpha + g0, rho + g0, sigma + g0, gc, jitter, c->W,
+                                     d_out3 + 3 * (size_t)g0, d_info + g0, c->d_ctr + 64);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     // Independent points fan out over `lanes` internal contexts (own workspaces and streams):
     // while one point is in its latency-bound panel phase or in the tail of a trailing update,
     // another point's bulk update fills the chip.  Lanes fork from / join into the caller's stream.
@@ -886,6 +958,38 @@ extern "C" int gpmi_logml(gpmi_ctx *c, const double *X, int n, int ldx, int D, c
     if (n <= 0 || !X || !y || !out3 || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
     double *dX, *dy;
     int rc;
+    if (small_logml(c, n, D)) {
+        // Small n, host buffers: X, y are copied (by the CPU) into a pinned, device-mapped buffer that the kernel
+        // reads directly, and the kernel writes (logml, sum log L_ii, z'z, info) straight into it: ONE launch and one
+        // stream synchronisation, no copy call in either direction (the four of the general path cost ~55 us,
+        // more than the kernel itself)
+        SeParams p;
+        if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
+        const size_t need = (8 + (size_t)n * (D + 1)) * sizeof(double);
+        if (need > c->h_pin_bytes) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
+            c->h_pin = c->h_pin_dev = nullptr;
+            c->h_pin_bytes = 0;
+            const size_t want = need > 65536 ? need : 65536;
+            if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
+                return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
+            HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
+            c->h_pin_bytes = want;
+        }
+        double *hX = c->h_pin + 8, *hy = hX + (size_t)n * D, *stage;
+        for (int d = 0; d < D; ++d) memcpy(hX + (size_t)d * n, X + (size_t)d * ldx, (size_t)n * sizeof(double));
+        memcpy(hy, y, (size_t)n * sizeof(double));
+        if ((rc = scratch_buf(c, (size_t)n * (D + 1) * sizeof(double), &stage))) return rc;
+        if ((rc = reserve_ws_small(c, n, 1))) return rc;
+        double *pd = c->h_pin_dev;
+        launch_logml_small(c->stream, pd + 8, n, n, pd + 8 + (size_t)n * D, p, sigma * sigma + jitter, c->W, (size_t)c->ld, pd,
+                           (int *)(pd + 3), c->d_info, stage);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(out3, c->h_pin, 3 * sizeof(double));
+        return *(const int *)(c->h_pin + 3);
+    }
     if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
     if ((rc = gpmi_logml_dev(c, dX, n, n, D, dy, alpha, ell, n_ell, sigma, jitter, c->d_out, c->d_info + 1))) return rc;
     int info = 0;
@@ -2194,9 +2298,20 @@ int probe_fused_read(hipStream_t s, unsigned long long *out5);
 extern "C" int gpmi_probe_fused(gpmi_ctx *c, double *out5)
 {
     ENTER(c);
-    unsigned long long h[5];
+    unsigned long long h[8];
     if (probe_fused_read(c->stream, h)) return gpmi_fail(GPMI_EHIP, "probe read failed");
     for (int i = 0; i < 5; ++i) out5[i] = (double)h[i];
+    return 0;
+}
+
+// out6: phase cycles of the one-workgroup small-N kernels since the last call (block 0 of every launch): build,
+// diagonal blocks, rows below, launches, trailing tiles, finalize
+extern "C" int gpmi_probe_small(gpmi_ctx *c, double *out6)
+{
+    ENTER(c);
+    unsigned long long h[8];
+    if (probe_fused_read(c->stream, h)) return gpmi_fail(GPMI_EHIP, "probe read failed");
+    for (int i = 0; i < 6; ++i) out6[i] = (double)h[i];
     return 0;
 }
 

@@ -9,6 +9,7 @@
 #define GPMI_FPACK_SLOTS 16   // per-context ring of such buffers: one per 128-column panel of an outer block
 #define GPMI_MAXD 8          // dimensions the register-resident fast path handles
 #define GPMI_MAXD_BIG 64     // dimensions the generic path handles (inverse length-scales in kernel arguments)
+#define GPMI_SMALL_PTS 128   // grid points per launch of the one-workgroup-per-point small-N kernel
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -31,6 +32,9 @@ struct gpmi_tuning {
     int block_recursive;
     int se_nt;            // non-temporal stores in k_se_cov<>
     int gemm_variant, rect_auto;  // A/B kernels: honoured by the probe build (-DGPMI_PROBES) only
+    int small_n;          // grids of marginal likelihoods at n <= small_n (and D <= GPMI_MAXD): one workgroup per point, one launch (0: off)
+    int small_n1;         // ... a single evaluation (or a grid of fewer than 6 points) up to this n: beyond it the multi-CU launch chain is faster
+    int small_m;          // partial factorisation of <= small_m rows: one workgroup, one launch (0: off)
 };
 void gpmi_tuning_defaults(gpmi_tuning *t);
 
@@ -53,6 +57,9 @@ struct gpmi_ctx {
     int ncu;                 // compute units of the device
     double *d_out;           // 3 doubles
     double *d_fin;           // slice sums of the finalize kernels
+    double *h_pin;           // pinned, device-mapped host buffer: inputs and results of small host-buffer calls travel without a copy call
+    double *h_pin_dev;       // its device address
+    size_t h_pin_bytes;
     // generic device staging buffers for the host-pointer API
     double *stage[4];
     size_t stage_bytes[4];
@@ -143,6 +150,14 @@ void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t ld
                     double *C, size_t ldc, int M, int N, int K, int accumulate_minus);
 void launch_syrk_uut(const gpmi_ctx *c, hipStream_t s, const double *U, size_t ldu, double *C, size_t ldc, int n);
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all);
+// small-N marginal likelihood: build + factorisation + solve + log-det by ONE workgroup per point
+void small_ws_layout(int n, size_t *ld, size_t *stride);
+void launch_logml_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
+                        double *W, size_t ld, double *d_out3, int *d_info_out, int *d_info_work,
+                        double *stage /* nullable: device staging for host-mapped X, y */);
+void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                              const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_out3,
+                              int *d_info_out, int *d_info_work);
 // inverses of L's 128 x 128 diagonal blocks (ceil(n / 128) x 128 x 128 doubles, tmp the same) from packed factors
 void launch_diag_inverses(hipStream_t s, const double *Fpack_all, int n, double *Dinv, double *tmp);
 // t = L^-1 k for ONE right-hand side in one launch (k_trsv_wave); k and t are different buffers of n doubles

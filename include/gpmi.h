@@ -311,6 +311,9 @@ GPMI_API int gpmi_probe_clock(gpmi_ctx *ctx, int reset, double *out3);
 /* Fused in-block launches since the last call, block 0: cycles in the sub-tile product, in the wait for the
  * other two sub-tiles, in the diagonal-block body; number of launches; sum of their K. */
 GPMI_API int gpmi_probe_fused(gpmi_ctx *ctx, double *out5);
+/* One-workgroup small-N kernels since the last call (block 0 of every launch): shader cycles in the covariance
+ * build, the diagonal blocks, the rows below, number of launches, cycles in the trailing tiles, in the finalize. */
+GPMI_API int gpmi_probe_small(gpmi_ctx *ctx, double *out6);
 
 /* MFMA f64 fragment-layout probe: D = A(16x4) * B(4x16) on one wave with the
  * library's fragment conventions; out256 row-major D[i][j].  Host buffers. */

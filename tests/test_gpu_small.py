@@ -1,0 +1,157 @@
+"""GPU: the one-workgroup small-N evaluation (k_logml_small / k_logml_small_batch / k_potrf_small) -- the sizes the
+reference's own drivers run the path at: N = 21 (R/tests.R:5-19), 79 .. 199 (pendulum_fit*.R:206-214), 256
+(BASELINE c1).  Parity against the oracle for EVERY n in 1 .. 256, agreement with the blocked multi-launch path
+(small_n = 0) where both exist, the batched grid in one launch, non-PD points, ARD and D up to 8."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+
+
+def _case(n, D, seed=0):
+    rng = np.random.default_rng(1000 * D + n + seed)
+    X = np.asfortranarray(rng.uniform(0.0, 1.0 + n / 40.0, (n, D)))
+    y = np.sin(X.sum(1)) + 0.1 * rng.standard_normal(n)
+    return X, y
+
+
+DEFAULTS = {"small_n": 256, "small_n1": 128, "small_m": 160}
+
+
+@pytest.fixture
+def one_wg(ctx):
+    """Force the one-workgroup kernels wherever they exist (by default a SINGLE evaluation above n = 128 and a
+    partial factorisation above 160 rows take the multi-CU launch chain, which is faster there)."""
+    ctx.set_option("small_n1", 256)
+    ctx.set_option("small_m", 640)
+    yield ctx
+    for k, v in DEFAULTS.items():
+        ctx.set_option(k, v)
+
+
+def test_small_logml_every_n_vs_oracle_and_blocked_path(one_wg, orc):
+    ctx = one_wg
+    worst_o = worst_b = 0.0
+    for n in range(1, 257):
+        X, y = _case(n, 1)
+        got = ctx.logml(X, y, 1.1, [0.7], 0.2)
+        want = orc.logml(X, y, 1.1, 0.7, 0.2)
+        assert want[3] == 0
+        e = max(abs(got[k] - want[k]) / max(abs(want[k]), 1e-300) for k in (1, 2))
+        e0 = abs(got[0] - want[0]) / abs(want[0])
+        assert e0 <= RTOL and e <= RTOL, (n, got, want)
+        worst_o = max(worst_o, e0)
+        if n % 5 == 1 or n > 250:
+            try:
+                ctx.set_option("small_n", 0)
+                ctx.set_option("small_m", 0)
+                blk = ctx.logml(X, y, 1.1, [0.7], 0.2)
+            finally:
+                ctx.set_option("small_n", 256)
+                ctx.set_option("small_m", 640)
+            eb = abs(got[0] - blk[0]) / abs(blk[0])
+            assert eb <= 1e-12, (n, got, blk)
+            worst_b = max(worst_b, eb)
+    print("small-N logml, n = 1..256: worst rel err vs oracle %.2e, vs the blocked path %.2e" % (worst_o, worst_b))
+
+
+@pytest.mark.parametrize("n,D", [(21, 1), (21, 3), (100, 2), (128, 3), (129, 1), (199, 1), (200, 5), (256, 8), (255, 4)])
+def test_small_logml_dims_and_ard(one_wg, orc, n, D):
+    ctx = one_wg
+    X, y = _case(n, D, 7)
+    ell = np.linspace(0.5, 1.5, D)
+    got = ctx.logml(X, y, 0.9, ell, 0.15, 1e-10)
+    want = orc.logml(X / ell, y, 0.9, 1.0, 0.15, 1e-10)   # ARD == isotropic rho = 1 on inputs scaled by 1 / ell
+    assert want[3] == 0 and abs(got[0] - want[0]) <= RTOL * abs(want[0]), (got, want)
+    # covariance arithmetic is shared with the big builder: the factor of the same matrix through gpmi_potrf
+    K = ctx.se_cov(X, None, 0.9, ell, 0.15 ** 2 + 1e-10)
+    L = np.linalg.cholesky(K)
+    z = np.linalg.solve(L, y)
+    ref = -0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * n * np.log(2 * np.pi)
+    assert abs(got[0] - ref) <= RTOL * abs(ref)
+
+
+def test_small_reference_known_answers(one_wg, golden):
+    ctx = one_wg
+    """K1 (the R/tests.R:5 grid, N = 21) and K2 (c1: N = 256) through the one-workgroup kernel."""
+    for kat in golden["kat"]["kats"]:
+        x = np.asarray(kat["x"], dtype=float)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        if x.shape[0] > 256 or x.shape[1] > 8:
+            continue
+        got = ctx.logml(x, np.asarray(kat["y"]), kat["alpha"], [kat["rho"]], kat["sigma"])
+        assert abs(got[0] - kat["logml"]) <= RTOL * abs(kat["logml"]), (kat["name"], got[0], kat["logml"])
+
+
+@pytest.mark.parametrize("n", [21, 128, 199, 256])
+def test_small_grid_is_one_launch_per_128_points_and_equals_single_calls(one_wg, orc, n):
+    ctx = one_wg
+    X, y = _case(n, 2, 3)
+    G = 150  # two launches: 128 + 22 points
+    rng = np.random.default_rng(5)
+    rho = rng.uniform(0.3, 2.0, G); sig = rng.uniform(0.05, 0.5, G); alpha = rng.uniform(0.5, 1.5, G)
+    rho[17] = 60.0; sig[17] = 1e-9   # not positive definite in fp64: NaN + info, the others unaffected
+    out, info = ctx.logml_grid(X, y, alpha, rho, sig)
+    assert info[17] > 0 and np.all(np.isnan(out[17]))
+    ok = np.arange(G) != 17
+    assert np.all(info[ok] == 0) and np.all(np.isfinite(out[ok]))
+    for g in (0, 1, 16, 18, 127, 128, 149):
+        single = ctx.logml(X, y, alpha[g], [rho[g]], sig[g])
+        assert tuple(out[g]) == tuple(single), (g, out[g], single)   # bit for bit
+    for g in (3, 140):
+        want = orc.logml(X, y, alpha[g], rho[g], sig[g])
+        assert abs(out[g, 0] - want[0]) <= RTOL * abs(want[0])
+
+
+def test_small_not_positive_definite_order(one_wg):
+    ctx = one_wg
+    """info = order of the first non-positive leading minor, as dpotrf / base-R chol() report it."""
+    n = 150
+    x = np.linspace(0, 1, n).reshape(-1, 1)
+    from gp_amd import NotPositiveDefinite
+    with pytest.raises(NotPositiveDefinite) as ei:
+        ctx.logml(x, np.zeros(n), 1.0, [50.0], 0.0)   # rank-deficient in fp64, no noise, no jitter
+    assert 1 <= ei.value.order <= n
+
+
+@pytest.mark.parametrize("n,m", [(25, 25), (79, 40), (199, 150), (120, 260)])
+def test_small_partial_factorisation_posteriors(one_wg, orc, n, m):
+    ctx = one_wg
+    """gpmi_gp_condition at pendulum sizes runs its augmented partial factorisation in ONE workgroup
+    (k_potrf_small, forced up to 640 rows here): against the reference's LU formula and the blocked path."""
+    rng = np.random.default_rng(n + m)
+    t = np.sort(rng.uniform(0, n / 10.0, n)); ts = np.sort(rng.uniform(0, n / 10.0, m))
+    y = np.sin(t) + 0.05 * rng.standard_normal(n)
+    a, l, s2, jit = 1.2, 1.0, 0.01, 1e-8
+    K = orc.deriv_cov("QQ", t, t, a, l); Ks = orc.deriv_cov("RQ", ts, t, a, l); Kss = orc.deriv_cov("RR", ts, ts, a, l)
+    Kd = K + s2 * np.eye(n)
+    mn_ref = Ks @ np.linalg.solve(Kd, y)
+    Kn_ref = Kss - Ks @ np.linalg.solve(Kd, Ks.T) + jit * np.eye(m)
+    mn, Kn = ctx.gp_condition(t, ts, y, a, l, s2, jit, "QQ", "RQ", "RR")
+    try:
+        ctx.set_option("small_m", 0)
+        mn_b, Kn_b = ctx.gp_condition(t, ts, y, a, l, s2, jit, "QQ", "RQ", "RR")
+    finally:
+        ctx.set_option("small_m", 640)
+    e1 = np.max(np.abs(mn - mn_ref)) / np.max(np.abs(mn_ref)); e2 = np.max(np.abs(Kn - Kn_ref)) / np.max(np.abs(Kn_ref))
+    print("gp_condition n=%d m=%d one workgroup: mn rel %.2e, Kn rel %.2e; vs blocked %.2e" %
+          (n, m, e1, e2, np.max(np.abs(Kn - Kn_b)) / np.max(np.abs(Kn_ref))))
+    assert e1 <= RTOL and e2 <= RTOL
+    assert np.max(np.abs(mn - mn_b)) <= 1e-11 * np.max(np.abs(mn_ref)) and np.max(np.abs(Kn - Kn_b)) <= 1e-11 * np.max(np.abs(Kn_ref))
+
+
+def test_default_thresholds_agree_across_the_switch_points(ctx, orc):
+    """Defaults: one evaluation takes the one-workgroup kernel up to n = 128 and the launch chain beyond, a grid of
+    >= 6 points the batched kernel up to n = 256: the results on either side of every switch agree to 1e-12."""
+    for k, v in DEFAULTS.items():
+        ctx.set_option(k, v)
+    for n in (127, 128, 129, 159, 160, 161, 255, 256, 257):
+        X, y = _case(n, 1, 11)
+        single = ctx.logml(X, y, 1.0, [0.8], 0.1)
+        out, info = ctx.logml_grid(X, y, np.ones(6), np.full(6, 0.8), np.full(6, 0.1))
+        want = orc.logml(X, y, 1.0, 0.8, 0.1)
+        assert np.all(info == 0) and abs(single[0] - want[0]) <= RTOL * abs(want[0])
+        assert np.max(np.abs(out[:, 0] - single[0])) <= 1e-12 * abs(single[0]), (n, out[:, 0], single)
