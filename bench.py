@@ -53,8 +53,6 @@ def parse_args(argv=None):
                          "rho x sigma grid at N=8192 sharded over the ranks (strong scaling); c5: derivative "
                          "joint [y, y'] covariance, N=8192 (matrix order 16384)")
     ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU (0 = auto)")
-    ap.add_argument("--lookahead", type=int, default=-1, choices=[-1, 0, 1],
-                    help="panel look-ahead inside one factorisation: 1 on, 0 off, -1 (default) library default")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
     ap.add_argument("--dry-run", action="store_true",
@@ -284,9 +282,6 @@ def main():
     dout = torch.zeros((npts, 3), dtype=torch.float64, device=dev)
     dinfo = torch.zeros(npts, dtype=torch.int32, device=dev)
 
-    if args.lookahead >= 0:
-        ctx.set_option("lookahead", args.lookahead)
-
     def run_points(lo, hi):
         """Evaluate points lo..hi-1 of this rank.  c3 / c4 go through the grid entry point, which
         overlaps independent points on internal lanes (own workspaces and streams)."""
@@ -348,7 +343,6 @@ def main():
     seq_ms = None
     if rank == 0:
         ctx.set_option("grid_lanes", 1)
-        ctx.set_option("lookahead", 0)   # nothing else on the chip while a bracketed launch runs
         ctx.set_option("kernel_timing", 1)
         ctx.kernel_timing(reset=True)
         nprof = min(steps * per_step, 4)
@@ -364,7 +358,6 @@ def main():
         ctx.set_option("kernel_timing", 0)
         # ... and the library's default one-at-a-time path (what a NUTS / optimiser loop sees: one
         # evaluation per step), without instrumentation
-        ctx.set_option("lookahead", args.lookahead)
         with torch.cuda.stream(stream):
             run_points(lo, lo + 1)
             torch.cuda.synchronize(dev)
@@ -493,7 +486,7 @@ def main():
                 "kernel": "k_gemm_nt<1> (trailing-update SYRK, v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma",
                 "measured_in": "instrumented sequential pass of the same evaluations in this run "
-                               "(lanes=1, look-ahead off: bracketed launches run alone on the chip)",
+                               "(lanes=1: bracketed launches run alone on the chip)",
                 "achieved": ach,
                 "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

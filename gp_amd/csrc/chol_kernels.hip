@@ -57,6 +57,7 @@ __device__ __host__ constexpr int fp_inv(int jb) { return 28 + jb; }
 #include "factor16.h"
 #include "se_device.h"
 
+#ifdef GPMI_PROBES  // the 5-wave / 3-barrier diagonal-block kernel of round 1 (diag_waves = 5): A/B material only
 // ---------------------------------------------------------------------------
 // Diagonal block (<= 128 x 128).  One workgroup of 5 waves:
 //   waves 0-3 "tile waves": wave w owns block-rows w and 7-w (9 register tiles, balanced),
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(320) void k_potrf_diag(double *__restrict__ A, size
 #undef GPMI_UPDATE_ROW
 #undef GPMI_STORE_ROW
 }
+
+#endif  // GPMI_PROBES
 
 // ---------------------------------------------------------------------------
 // Diagonal block, 4-wave variant: the same algorithm with THREE tile waves (block-rows
@@ -484,6 +487,9 @@ __device__ __forceinline__ bool syrk_tile(int b, int T, int TN, int order, int &
         tj = b - i * (i + 1) / 2;
         return ti < T;
     }
+#ifndef GPMI_PROBES
+    return false;  // the XCD-grouped super-tile walk (measured slower in place) exists in the probe build only
+#else
     const int xcd = b & 7, q = b >> 3;
     const int s = (q / (ST * ST)) * 8 + xcd;       // super-tile index, row-major over the triangle
     const int local = q % (ST * ST);
@@ -496,6 +502,7 @@ __device__ __forceinline__ bool syrk_tile(int b, int T, int TN, int order, int &
     ti = I * ST + (local % ST);
     tj = J * ST + (local / ST);
     return ti < T && tj <= ti;
+#endif
 }
 __host__ inline int syrk_grid(int T, int TN, int order)
 {
@@ -1786,8 +1793,8 @@ __global__ __launch_bounds__(512) void k_pack_factors(const double *__restrict__
 // Publication needs no flag: the output vector is pre-filled with an all-ones bit pattern (a NaN no
 // arithmetic produces: a computed NaN is stored as the canonical quiet NaN), every consumer thread polls ITS
 // element with agent-scope loads until it is no longer the pattern, and 64-bit agent-scope stores are
-// single-copy atomic.  A workgroup waits only for workgroups of lower index, which are dispatched before it:
-// the waits cannot deadlock, whatever the number of resident workgroups.
+// single-copy atomic.  Block-rows are handed out by a device ticket in START order, so a workgroup waits only for
+// workgroups that are already running: the waits cannot deadlock, whatever the dispatch order or residency.
 // Sums in a fixed order: deterministic.
 // ---------------------------------------------------------------------------
 constexpr int TSV = 128;
@@ -1814,11 +1821,22 @@ __global__ __launch_bounds__(256) void k_transpose_blocks(const double *__restri
 
 __global__ __launch_bounds__(256) void k_trsv_wave(const double *__restrict__ L, size_t ldl, int n,
                                                    const double *__restrict__ k, double *__restrict__ t,
-                                                   const double *__restrict__ Dinv)
+                                                   const double *__restrict__ Dinv, int *__restrict__ ticket)
 {
     __shared__ double ts[TSV];
     __shared__ double red[2][TSV];
-    const int w = blockIdx.x, tid = threadIdx.x, r = tid & (TSV - 1), h = tid >> 7;
+    __shared__ int s_w;
+    // Block-row by TICKET, not by blockIdx: HIP promises no dispatch order (each XCD deals its share of the grid
+    // independently), so "lower blockIdx started earlier" is not a guarantee.  A workgroup that draws ticket w waits
+    // only for tickets < w -- workgroups that have already STARTED, are resident and make progress -- whatever the
+    // dispatch order and whatever else shares the chip.  The workgroup drawing the last ticket re-arms the counter
+    // (the next launch is stream-ordered behind this one).
+    if (threadIdx.x == 0) {
+        s_w = atomicAdd(ticket, 1);
+        if (s_w == (int)gridDim.x - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int w = s_w, tid = threadIdx.x, r = tid & (TSV - 1), h = tid >> 7;
     const int row = w * TSV + r;
     const bool rok = row < n;
     const size_t rowc = (size_t)(rok ? row : n - 1);
@@ -2029,7 +2047,7 @@ static void small_lds_attr()
 
 void gpmi_tuning_defaults(gpmi_tuning *t)
 {
-    t->syrk_order = 0;
+    t->syrk_order = 0;  // (probe build only)
     t->stagger = (2 << 16) | 4;
     t->fuse_diag = 15;
     t->diag_waves = 4;
@@ -2144,7 +2162,11 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
     const int T = (M + GT - 1) / GT;
     // N < M: lower trapezoid (block column of a look-ahead update), row-major order only
     const int TNf = (N + GT - 1) / GT, TN = TNf < T ? TNf : T;
+#ifdef GPMI_PROBES
     const int syrk_order = TN < T ? 0 : c->tune.syrk_order;
+#else
+    const int syrk_order = 0;  // row-major walk of the lower triangle / trapezoid
+#endif
     const int ntiles = syrk_grid(T, TN, syrk_order);
     const int stg = ntiles >= 1024 ? c->tune.stagger : 0;  // only when every CU holds two workgroups for many rounds
 #ifdef GPMI_PROBES
@@ -2225,10 +2247,12 @@ static void panel_one(gpmi_ctx *c, double *W, size_t ld, int *d_info, double *Fp
 {
     double *Fp = fpack_slot(c, Fpack_all, ko, k);
     if (with_diag) {
-        if (c->tune.diag_waves == 4)
-            hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
-        else
+#ifdef GPMI_PROBES
+        if (c->tune.diag_waves == 5)
             hipLaunchKernelGGL(k_potrf_diag, dim3(1), 320, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
+        else
+#endif
+            hipLaunchKernelGGL(k_potrf_diag4, dim3(1), 256, 0, s, W + (size_t)k + (size_t)k * ld, ld, kb, Fp, d_info, k);
     }
     const int r0 = k + kb;
     const int rlo = r0 > row_lo ? r0 : row_lo;
@@ -2323,15 +2347,18 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
         return cols >= c->tune.nb_thr[0] ? 1024 : (cols >= c->tune.nb_thr[1] ? 512 : (cols >= c->tune.nb_thr[2] ? 256 : 128));
     };
     const int NBO = c->nb_outer > 0 ? c->nb_outer : nbo_for(ncol);
-    // look-ahead needs at least three outer blocks to pay, a second stream, and the block's packed
-    // factors in the ring (or all kept)
+#ifdef GPMI_PROBES
+    // (probe build) two-stream look-ahead over outer blocks: needs at least three outer blocks to pay, a second
+    // stream, and the block's packed factors in the ring (or all kept); measured not to pay, DESIGN section 4
     bool la = c->lookahead > 0 && nfac >= 3 * NBO && (Fpack_all || NBO / GPMI_NB <= GPMI_FPACK_SLOTS);
     if (la) {
         int rc = gpmi_lookahead_streams(c);
         if (rc) return rc;
         la = c->nq >= 2 || c->pstream;
     }
-    if (!la) {
+    if (!la)
+#endif
+    {
         hipStream_t s = c->stream;
         // auto width follows the order of the matrix still to update (tune.nb_adapt): the last blocks of a
         // large matrix are a small matrix, whose few trailing tiles do not fill the chip at K = 1024
@@ -2362,7 +2389,9 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
                        syrk_grid(T, TN, 0) > 2 * (c->ncu > 0 ? c->ncu : 256));
             }
         }
-    } else {
+    }
+#ifdef GPMI_PROBES
+    else {
         // Look-ahead over outer blocks on TWO streams.  With U(j) the trailing update by block j,
         // split by columns into U1(j) (block column j + 1, all rows below) and U2(j) (the rest):
         //   sB (panel stream): P(0) | U1(0) P(1) | U1(1) P(2) | ...   U1(j) waits for U2(j - 1)
@@ -2379,16 +2408,16 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             sA = c->qstream[0];
             sB = c->qstream[1];
         }
-        hipEventRecord(c->evM, caller);
-        if (sA != caller) hipStreamWaitEvent(sA, c->evM, 0);
-        hipStreamWaitEvent(sB, c->evM, 0);
+        (void)hipEventRecord(c->evM, caller);
+        if (sA != caller) (void)hipStreamWaitEvent(sA, c->evM, 0);
+        (void)hipStreamWaitEvent(sB, c->evM, 0);
         {
             const int ke0 = NBO < nfac ? NBO : nfac;
             kt_begin(c, 2, sB);
             panel_rows(c, W, ld, d_info, Fpack_all, 0, ke0, NBO, 0, M, true, sB);
             const double w = (double)ke0, m = (double)M;
             kt_end(c, 2, w * w * (m - w) + w * w * w / 3.0, sB);
-            hipEventRecord(c->evP, sB);
+            (void)hipEventRecord(c->evP, sB);
         }
         bool u2_pending = false;
         for (int ko = 0; ko < nfac; ko += NBO) {
@@ -2397,7 +2426,7 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             if (ke >= M || ke >= ncol) break;
             const double *Pj = W + (size_t)ko * ld;   // panel j: rows [ke, M) of columns [ko, ke)
             if (ke >= nfac) {  // last factored block: Schur complement / augmented rows, nothing follows
-                hipStreamWaitEvent(sA, c->evP, 0);
+                (void)hipStreamWaitEvent(sA, c->evP, 0);
                 const double mt = (double)(ncol - ke), extra = (double)(M - ncol);
                 kt_begin(c, 1, sA);
                 launch_syrk_lower(c, sA, Pj + ke, ld, W + (size_t)ke + (size_t)ke * ld, ld, M - ke, ncol - ke, K, c->d_ctr, c->ncu);
@@ -2407,7 +2436,7 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             const int ke2 = (ke + NBO < nfac) ? ke + NBO : nfac;
             const int w1 = ke2 - ke;
             // U1(j) on sB: rows [ke, M) x columns [ke, ke2); its tile (0, 0) is the next diagonal block
-            if (u2_pending) hipStreamWaitEvent(sB, c->evU, 0);
+            if (u2_pending) (void)hipStreamWaitEvent(sB, c->evU, 0);
             FuseDiag fd{fpack_slot(c, Fpack_all, ke, ke), d_info, ke, (nfac - ke < GPMI_NB) ? nfac - ke : GPMI_NB, nullptr};
             kt_begin(c, 1, sB);
             const bool fused = launch_syrk_lower(c, sB, Pj + ke, ld, W + (size_t)ke + (size_t)ke * ld, ld, M - ke, w1, K, c->d_ctr,
@@ -2416,12 +2445,12 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
             // U2(j) on sA: rows [ke2, M) x columns [ke2, ncol)
             u2_pending = false;
             if (ke2 < M && ke2 < ncol) {
-                hipStreamWaitEvent(sA, c->evP, 0);
+                (void)hipStreamWaitEvent(sA, c->evP, 0);
                 const double mt = (double)(ncol - ke2), extra = (double)(M - ncol);
                 kt_begin(c, 1, sA);
                 launch_syrk_lower(c, sA, Pj + ke2, ld, W + (size_t)ke2 + (size_t)ke2 * ld, ld, M - ke2, ncol - ke2, K, c->d_ctr, c->ncu);
                 kt_end(c, 1, (mt * (mt + 1.0) + 2.0 * extra * mt) * (double)K, sA);
-                hipEventRecord(c->evU, sA);
+                (void)hipEventRecord(c->evU, sA);
                 u2_pending = true;
             }
             // P(j + 1) on sB
@@ -2431,15 +2460,16 @@ int launch_potrf_partial(gpmi_ctx *c, double *W, size_t ld, int M, int ncol, int
                 const double w = (double)w1, m = (double)(M - ke);
                 kt_end(c, 2, w * w * (m - w) + w * w * w / 3.0, sB);
             }
-            hipEventRecord(c->evP, sB);
+            (void)hipEventRecord(c->evP, sB);
         }
         if (sA != caller) {
-            hipEventRecord(c->evM, sA);
-            hipStreamWaitEvent(caller, c->evM, 0);
+            (void)hipEventRecord(c->evM, sA);
+            (void)hipStreamWaitEvent(caller, c->evM, 0);
         }
-        hipEventRecord(c->evU, sB);
-        hipStreamWaitEvent(caller, c->evU, 0);
+        (void)hipEventRecord(c->evU, sB);
+        (void)hipStreamWaitEvent(caller, c->evU, 0);
     }
+#endif  // GPMI_PROBES
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "potrf launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -2528,12 +2558,13 @@ void launch_diag_inverses(hipStream_t s, const double *Fpack_all, int n, double 
 }
 
 // t = L^-1 k (k, t: n contiguous doubles, different buffers) in one launch; Dinv from launch_diag_inverses
-int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *k, double *t, const double *Dinv)
+int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *k, double *t, const double *Dinv,
+                      int *ticket /* zeroed device int owned by the calling context; left zero */)
 {
     if (n <= 0) return 0;
     hipError_t e = hipMemsetAsync(t, 0xff, (size_t)n * sizeof(double), s);  // "not yet" in every element
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "memset failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_trsv_wave, dim3((n + TSV - 1) / TSV), 256, 0, s, L, ldl, n, k, t, Dinv);
+    hipLaunchKernelGGL(k_trsv_wave, dim3((n + TSV - 1) / TSV), 256, 0, s, L, ldl, n, k, t, Dinv, ticket);
     e = hipGetLastError();
     if (e != hipSuccess) return gpmi_fail(GPMI_EHIP, "trsv launch failed: %s", hipGetErrorString(e));
     return 0;

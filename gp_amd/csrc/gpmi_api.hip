@@ -73,22 +73,22 @@ void kt_begin(gpmi_ctx *c, int cat, hipStream_t st)
     if (!c->ktiming) return;
     KTimer *k = (KTimer *)c->ktimer;
     if (k->used[cat] == k->a[cat].size()) {
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
         k->a[cat].push_back(e0);
         k->b[cat].push_back(e1);
         k->w[cat].push_back(0.0);
         k->flag[cat].push_back(0);
     }
-    hipEventRecord(k->a[cat][k->used[cat]], st ? st : c->stream);
+    (void)hipEventRecord(k->a[cat][k->used[cat]], st ? st : c->stream);
 }
 
 void kt_end(gpmi_ctx *c, int cat, double work, hipStream_t st, int flag)
 {
     if (!c->ktiming) return;
     KTimer *k = (KTimer *)c->ktimer;
-    hipEventRecord(k->b[cat][k->used[cat]], st ? st : c->stream);
+    (void)hipEventRecord(k->b[cat][k->used[cat]], st ? st : c->stream);
     k->w[cat][k->used[cat]] = work;
     k->flag[cat][k->used[cat]] = (char)flag;
     k->used[cat]++;
@@ -217,6 +217,21 @@ static int enter(gpmi_ctx *c)
         if (rc_) return rc_;     \
     } while (0)
 
+extern "C" int gpmi_destroy(gpmi_ctx *c);
+
+// HIP call inside gpmi_create: on failure everything allocated so far is released (gpmi_destroy
+// accepts a partially built context: every member is null-checked)
+#define CREATE_CHK(expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            const int rc_ = gpmi_fail(e_ == hipErrorOutOfMemory ? GPMI_ENOMEM : GPMI_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                                      hipGetErrorString(e_), __FILE__, __LINE__);                 \
+            gpmi_destroy(c);                                                                      \
+            return rc_;                                                                           \
+        }                                                                                         \
+    } while (0)
+
 extern "C" int gpmi_create(gpmi_ctx **out, int device)
 {
     if (!out) return gpmi_fail(GPMI_EARG, "ctx out pointer is NULL");
@@ -238,65 +253,71 @@ extern "C" int gpmi_create(gpmi_ctx **out, int device)
     c->pid = (int)getpid();
     gpmi_tuning_defaults(&c->tune);
     c->nb_outer = 0;  // auto
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    {
-        HIPCHK(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->evU, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
-        c->lookahead = -1;  // -1: auto (see launch_potrf_partial), 0: off, 1: on
-        c->calibrate = 1;
-    }
-    HIPCHK(hipMalloc((void **)&c->Fpack, (size_t)GPMI_FPACK_SLOTS * GPMI_FPACK * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&c->d_info, 64));
-    HIPCHK(hipMalloc((void **)&c->d_ctr, 2048));
-    HIPCHK(hipMemsetAsync(c->d_ctr, 0, 2048, c->own_stream));
-    HIPCHK(hipStreamSynchronize(c->own_stream));
+    c->lookahead = 0; // (probe build: two-stream look-ahead over outer blocks, opt-in)
+    c->calibrate = 1;
     c->ncu = prop.multiProcessorCount;
-    HIPCHK(hipMalloc((void **)&c->d_out, 64));
-    HIPCHK(hipMalloc((void **)&c->d_fin, 65536));  // slice sums of the finalize kernels: 2 doubles per 256 rows
-    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    // test hook: GPMI_FAIL_CREATE_AT=k makes the k-th resource acquisition below fail (leak tests of the unwind path)
+    int step = 0;
+    const char *fail_env = getenv("GPMI_FAIL_CREATE_AT");
+    const int fail_at = fail_env ? atoi(fail_env) : 0;
+#define CREATE_STEP(expr) CREATE_CHK((++step == fail_at) ? hipErrorOutOfMemory : (expr))
+    CREATE_STEP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CREATE_STEP(hipEventCreateWithFlags(&c->evP, hipEventDisableTiming));
+    CREATE_STEP(hipEventCreateWithFlags(&c->evU, hipEventDisableTiming));
+    CREATE_STEP(hipEventCreateWithFlags(&c->evM, hipEventDisableTiming));
+    CREATE_STEP(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    CREATE_STEP(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    CREATE_STEP(hipMalloc((void **)&c->Fpack, (size_t)GPMI_FPACK_SLOTS * GPMI_FPACK * sizeof(double)));
+    CREATE_STEP(hipMalloc((void **)&c->d_info, 64));
+    CREATE_STEP(hipMalloc((void **)&c->d_ctr, 2048));
+    CREATE_STEP(hipMemsetAsync(c->d_ctr, 0, 2048, c->own_stream));
+    CREATE_STEP(hipStreamSynchronize(c->own_stream));
+    CREATE_STEP(hipMalloc((void **)&c->d_out, 64));
+    CREATE_STEP(hipMalloc((void **)&c->d_fin, 65536));  // slice sums of the finalize kernels: 2 doubles per 256 rows
+    for (int i = 0; i < 4; ++i) CREATE_STEP(hipEventCreate(&c->ev[i]));
+#undef CREATE_STEP
     *out = c;
     return 0;
 }
 
+// Releases everything a context owns; every member may be null (partially built context of a failed gpmi_create).
 extern "C" int gpmi_destroy(gpmi_ctx *c)
 {
     if (!c) return 0;
     if (c->pid == (int)getpid()) {
-        hipSetDevice(c->device);
-        hipStreamSynchronize(c->stream);
-        hipFree(c->W);
-        hipFree(c->Fpack);
-        hipFree(c->d_info);
-        hipFree(c->d_ctr);
-        hipFree(c->itp_L);
-        hipFree(c->itp_dL);
-        hipFree(c->itp_part);
-        free(c->itp_lp);
-        hipFree(c->d_out);
-        hipFree(c->d_fin);
-        if (c->h_pin) (void)hipHostFree(c->h_pin);
-        hipFree(c->scratch);
-        for (int i = 0; i < 4; ++i) {
-            hipFree(c->stage[i]);
-            hipEventDestroy(c->ev[i]);
-        }
-        if (c->pstream) {
-            hipStreamSynchronize(c->pstream);
-            hipStreamDestroy(c->pstream);
-        }
-        hipEventDestroy(c->evM);
-        hipEventDestroy(c->evFork);
-        hipEventDestroy(c->evJoin);
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
         for (int l = 0; l < 7; ++l)
             if (c->lane[l]) gpmi_destroy(c->lane[l]);
-        for (int q = 0; q < c->nq; ++q) hipStreamDestroy(c->qstream[q]);
-        hipEventDestroy(c->evP);
-        hipEventDestroy(c->evU);
-        hipStreamDestroy(c->own_stream);
+        double *dev_bufs[] = {c->W, c->Fpack, c->itp_L, c->itp_dL, c->itp_part, c->d_out, c->d_fin, c->scratch,
+                              c->stage[0], c->stage[1], c->stage[2], c->stage[3]};
+        for (double *b : dev_bufs)
+            if (b) (void)hipFree(b);
+        if (c->d_info) (void)hipFree(c->d_info);
+        if (c->d_ctr) (void)hipFree(c->d_ctr);
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        free(c->itp_lp);
+        if (c->ktimer) {  // per-kernel timing events (gpmi_set_option "kernel_timing")
+            KTimer *k = (KTimer *)c->ktimer;
+            for (int cat = 0; cat < 3; ++cat) {
+                for (hipEvent_t e : k->a[cat])
+                    if (e) (void)hipEventDestroy(e);
+                for (hipEvent_t e : k->b[cat])
+                    if (e) (void)hipEventDestroy(e);
+            }
+            delete k;
+        }
+        hipEvent_t evs[] = {c->ev[0], c->ev[1], c->ev[2], c->ev[3], c->evM, c->evFork, c->evJoin, c->evP, c->evU};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        if (c->pstream) {
+            (void)hipStreamSynchronize(c->pstream);
+            (void)hipStreamDestroy(c->pstream);
+        }
+        for (int q = 0; q < c->nq; ++q)
+            if (c->qstream[q]) (void)hipStreamDestroy(c->qstream[q]);
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
     free(c);
     return 0;
@@ -337,11 +358,6 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     }
     if (!strcmp(name, "stagger")) {
         c->tune.stagger = value;
-        return 0;
-    }
-    if (!strcmp(name, "diag_waves")) {
-        if (value != 4 && value != 5) return gpmi_fail(GPMI_EARG, "diag_waves must be 4 or 5");
-        c->tune.diag_waves = value;
         return 0;
     }
     if (!strcmp(name, "se_nt")) {
@@ -385,11 +401,25 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->tune.small_m = value;
         return 0;
     }
-    if (!strcmp(name, "syrk_order")) {
+#ifdef GPMI_PROBES
+    // switches of measured-and-rejected variants, kept as A/B material in the probe build only
+    if (!strcmp(name, "syrk_order")) {   // 1: XCD-grouped 8 x 8 super-tile walk of the SYRK triangle
         c->tune.syrk_order = value != 0;
         return 0;
     }
-#ifdef GPMI_PROBES
+    if (!strcmp(name, "diag_waves")) {   // 5: the 5-wave / 3-barrier diagonal-block kernel of round 1
+        if (value != 4 && value != 5) return gpmi_fail(GPMI_EARG, "diag_waves must be 4 or 5");
+        c->tune.diag_waves = value;
+        return 0;
+    }
+    if (!strcmp(name, "lookahead")) {    // 1: two-stream look-ahead over outer blocks inside one factorisation
+        c->lookahead = value > 0;
+        return 0;
+    }
+    if (!strcmp(name, "lane_lookahead")) {
+        c->lane_lookahead = value != 0;
+        return 0;
+    }
     if (!strcmp(name, "rect_auto")) {
         c->tune.rect_auto = value;
         return 0;
@@ -420,17 +450,9 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->calibrate = value != 0;
         return 0;
     }
-    if (!strcmp(name, "lane_lookahead")) {
-        c->lane_lookahead = value != 0;
-        return 0;
-    }
     if (!strcmp(name, "grid_lanes")) {
         if (value < 0 || value > 8) return gpmi_fail(GPMI_EARG, "grid_lanes must be 0 (auto) .. 8");
         c->grid_lanes = value;
-        return 0;
-    }
-    if (!strcmp(name, "lookahead")) {  // panel look-ahead on two streams: 1 on, 0 off, -1 auto (default)
-        c->lookahead = value;
         return 0;
     }
     if (!strcmp(name, "timing")) {
@@ -676,7 +698,7 @@ extern "C" int gpmi_joint_cov(gpmi_ctx *c, const double *t, int n, double alpha,
 // ---- factorisation ------------------------------------------------------------
 static void tic(gpmi_ctx *c, int i)
 {
-    if (c->timing) hipEventRecord(c->ev[i], c->stream);
+    if (c->timing) (void)hipEventRecord(c->ev[i], c->stream);
 }
 
 extern "C" int gpmi_potrf_dev(gpmi_ctx *c, double *dA, int n, int lda, int *d_info)
@@ -758,7 +780,7 @@ extern "C" int gpmi_trsv_lower(gpmi_ctx *c, const double *L, int n, int ldl, con
     HIPCHK(hipMemcpyAsync(db, b, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     launch_pack_factors(s, dL, (size_t)ldd, n, Fall);
     launch_diag_inverses(s, Fall, n, Dinv, Dinv + dinv);
-    if ((rc = launch_trsv_lower(s, dL, (size_t)ldd, n, db, dx, Dinv))) return rc;  // one launch, the factor read once
+    if ((rc = launch_trsv_lower(s, dL, (size_t)ldd, n, db, dx, Dinv, c->d_ctr + 32))) return rc;  // one launch, the factor read once
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(z, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -795,11 +817,11 @@ static void lanes_fork(gpmi_ctx *c, int lanes, hipStream_t caller)
     if (lanes <= 1) return;
     c->lookahead = c->lane_lookahead;
     const bool useq = c->calibrate && c->nq > 1;
-    hipEventRecord(c->evFork, caller);
+    (void)hipEventRecord(c->evFork, caller);
     for (int l = 0; l < lanes; ++l) {
         gpmi_ctx *lc = l ? c->lane[l - 1] : c;
         lc->stream = useq ? c->qstream[l % c->nq] : (l ? lc->own_stream : caller);
-        if (lc->stream != caller) hipStreamWaitEvent(lc->stream, c->evFork, 0);
+        if (lc->stream != caller) (void)hipStreamWaitEvent(lc->stream, c->evFork, 0);
     }
 }
 
@@ -810,8 +832,8 @@ static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
     for (int l = 0; l < lanes; ++l) {
         gpmi_ctx *lc = l ? c->lane[l - 1] : c;
         if (lc->stream != caller) {
-            hipEventRecord(lc->evJoin, lc->stream);
-            hipStreamWaitEvent(caller, lc->evJoin, 0);
+            (void)hipEventRecord(lc->evJoin, lc->stream);
+            (void)hipStreamWaitEvent(caller, lc->evJoin, 0);
         }
         lc->stream = l ? lc->own_stream : caller;
     }
@@ -999,8 +1021,7 @@ extern "C" int gpmi_logml(gpmi_ctx *c, const double *X, int n, int ldx, int D, c
     if (c->timing) {
         float ms;
         for (int i = 0; i < 3; ++i) {
-            hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
-            c->last_ms[i] = ms;
+            c->last_ms[i] = (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) ? ms : 0.0;
         }
     }
     return info;
@@ -1204,9 +1225,9 @@ extern "C" int gpmi_interp_free(gpmi_ctx *c)
 {
     ENTER(c);
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(c->itp_L);
-    hipFree(c->itp_dL);
-    hipFree(c->itp_part);
+    if (c->itp_L) (void)hipFree(c->itp_L);
+    if (c->itp_dL) (void)hipFree(c->itp_dL);
+    if (c->itp_part) (void)hipFree(c->itp_part);
     free(c->itp_lp);
     c->itp_L = c->itp_dL = c->itp_part = nullptr;
     c->itp_lp = nullptr;
@@ -2033,16 +2054,16 @@ extern "C" int gpmi_seq_destroy(gpmi_seq *q)
     if (!q) return 0;
     gpmi_ctx *c = q->c;
     if (c && c->pid == (int)getpid()) {
-        hipSetDevice(c->device);
-        hipStreamSynchronize(c->stream);
-        hipFree(q->dX);
-        hipFree(q->L);
-        hipFree(q->Fall);
-        hipFree(q->Dinv);
-        hipFree(q->B);
-        hipFree(q->Kx);
-        hipFree(q->Ls);
-        hipFree(q->u);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (q->dX) (void)hipFree(q->dX);
+        if (q->L) (void)hipFree(q->L);
+        if (q->Fall) (void)hipFree(q->Fall);
+        if (q->Dinv) (void)hipFree(q->Dinv);
+        if (q->B) (void)hipFree(q->B);
+        if (q->Kx) (void)hipFree(q->Kx);
+        if (q->Ls) (void)hipFree(q->Ls);
+        if (q->u) (void)hipFree(q->u);
     }
     free(q);
     return 0;
@@ -2135,7 +2156,7 @@ extern "C" int gpmi_seq_create(gpmi_ctx *c, gpmi_seq **out, const double *X, int
     launch_transpose(s, U, ldm, dKn, ldm, n, n);
     hipLaunchKernelGGL(k_seq_b, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, U, dKn, ldm, q->B, n);
     // b = L^-1 mn (:56)
-    SEQ_TRY(launch_trsv_lower(s, q->L, ldm, n, q->u, q->a, q->Dinv))
+    SEQ_TRY(launch_trsv_lower(s, q->L, ldm, n, q->u, q->a, q->Dinv, c->d_ctr + 32))
     if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "sampler set-up launch");
     int info = 0;
     if ((e = hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess)
@@ -2165,7 +2186,7 @@ extern "C" int gpmi_seq_step(gpmi_seq *q, const double *xs, double *out2)
     double *ti = q->Kx + (size_t)i * n;
     int rc;
     launch_se_cov(c, s, q->dX, n, n, q->Xs + i, 1, ms, q->p, 0.0, 0, q->kcol, (size_t)n);  // K_XsX row (:71)
-    if ((rc = launch_trsv_lower(s, q->L, q->ldm, n, q->kcol, ti, q->Dinv))) return rc;    // t_i = L^-1 k_i, one launch
+    if ((rc = launch_trsv_lower(s, q->L, q->ldm, n, q->kcol, ti, q->Dinv, q->c->d_ctr + 32))) return rc;    // t_i = L^-1 k_i, one launch
     seq_mv(q, s, q->B, q->ldm, ti, 1.0, q->u);
     hipLaunchKernelGGL(k_seq_dots, dim3(i + 2), 256, 0, s, q->Kx, n, i, q->u, q->a, q->Xs, ms, q->p, q->jitter, q->ks);
     hipLaunchKernelGGL(k_seq_cond, dim3(1), 256, (size_t)(i + 1) * sizeof(double), s, q->Ls, ms, i, q->ks, ms, q->w,

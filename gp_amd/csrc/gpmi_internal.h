@@ -22,10 +22,10 @@ struct SeParams {            // squared-exponential hyper-parameters, kernel-arg
 // Algorithm switches of one context (gpmi_set_option).  Per context, never process-global: two
 // contexts or two host threads do not change each other's algorithm; grid lanes copy their root's.
 struct gpmi_tuning {
-    int syrk_order;       // 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
+    int syrk_order;       // (probe build only) 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
     int stagger;          // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup of a CU pair
-    int fuse_diag;        // bit 0: in-block GEMMs, bit 1: trailing SYRK (multi-round), bit 2: sub-tiled diagonal tile, bit 3: single-round SYRK (sub-tiled)
-    int diag_waves;       // 4: k_potrf_diag4 (default), 5: k_potrf_diag
+    int fuse_diag;        // default 15; bit 0: in-block GEMMs, bit 1: trailing SYRK (multi-round), bit 2: sub-tiled diagonal tile, bit 3: single-round SYRK (sub-tiled)
+    int diag_waves;       // (probe build only) 4: k_potrf_diag4 (default), 5: k_potrf_diag
     int nb_adapt;         // outer-block width re-chosen per block from the order of the matrix still to update
     int nb_thr[3];        // ... >= nb_thr[0]: 1024 columns, >= nb_thr[1]: 512, >= nb_thr[2]: 256, below: 128
     int ksplit, ksplit_max;
@@ -64,7 +64,7 @@ struct gpmi_ctx {
     double *stage[4];
     size_t stage_bytes[4];
     int nb_outer;            // outer panel width (multiple of GPMI_NB)
-    int lookahead;           // two-stream look-ahead over outer blocks: -1 auto, 0 off, 1 on
+    int lookahead;           // (probe build only) two-stream look-ahead over outer blocks: 0 off (default), 1 on
     hipStream_t pstream;     // panel stream of the look-ahead when no calibrated pair exists
     hipEvent_t evM;
     hipEvent_t evP, evU;     // panel done / next-panel columns updated
@@ -161,7 +161,8 @@ void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, i
 // inverses of L's 128 x 128 diagonal blocks (ceil(n / 128) x 128 x 128 doubles, tmp the same) from packed factors
 void launch_diag_inverses(hipStream_t s, const double *Fpack_all, int n, double *Dinv, double *tmp);
 // t = L^-1 k for ONE right-hand side in one launch (k_trsv_wave); k and t are different buffers of n doubles
-int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *k, double *t, const double *Dinv);
+int launch_trsv_lower(hipStream_t s, const double *L, size_t ldl, int n, const double *k, double *t, const double *Dinv,
+                      int *ticket /* zeroed device int of the calling context (d_ctr + 32) */);
 void launch_get_row(hipStream_t s, const double *W, size_t ld, int row, int col0, int m, double scale, double *out);
 void launch_logml_finalize(hipStream_t s, const double *W, size_t ld, int n, int zrow,
                            const int *d_info, double *d_out3, int *d_info_out, double *part /* 2 ceil(n/256) doubles */);

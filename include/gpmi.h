@@ -84,9 +84,11 @@ GPMI_API int gpmi_sync(gpmi_ctx *ctx);
 /* pre-size the factorisation workspace for matrices of order <= n_max */
 GPMI_API int gpmi_reserve(gpmi_ctx *ctx, int n_max);
 /* algorithm switches of THIS context (never process-global): "nb_outer" (outer panel width, multiple
- * of 128, 0 = auto), "grid_lanes", "lookahead", "fuse_diag", "ksplit", "block_recursive", "diag_waves",
- * "syrk_order", "stagger", "se_nt", "nb_adapt", "nb_thr1024", "nb_thr512", "nb_thr256", "calibrate", "timing", "kernel_timing"; unknown
- * names return GPMI_EARG */
+ * of 128, 0 = auto), "grid_lanes", "fuse_diag", "ksplit", "block_recursive", "stagger", "se_nt", "nb_adapt",
+ * "nb_thr1024", "nb_thr512", "nb_thr256", "small_n", "small_n1", "small_m" (one-workgroup kernels for small
+ * problems), "calibrate", "timing", "kernel_timing"; unknown names return GPMI_EARG.  Switches of variants that
+ * were measured and rejected ("lookahead", "syrk_order", "diag_waves", "gemm_variant", ...) exist in the probe
+ * build only. */
 GPMI_API int gpmi_set_option(gpmi_ctx *ctx, const char *name, int value);
 
 /* ---- covariance builders ---------------------------------------------- */

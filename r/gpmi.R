@@ -15,7 +15,10 @@ gpmi_kernels_env <- local({
   QR <- function(x, y, phi) .Call("gpmi_R_deriv_cov", 1L, as.double(x), as.double(y), phi[[1]], phi[[2]], 0L)
   RR <- function(x, y, phi) .Call("gpmi_R_deriv_cov", 3L, as.double(x), as.double(y), phi[[1]], phi[[2]],
                                   if (compat_kernels_R_RR) GPMI_COMPAT_RR else 0L)
-  QQard <- function(X, Y, phi) .Call("gpmi_R_se_cov", as.matrix(X), as.matrix(Y), phi[[1]], as.double(phi[[2]]))
+  QQard <- function(X, Y, phi) {
+    X <- as.matrix(X); Y <- as.matrix(Y); storage.mode(X) <- "double"; storage.mode(Y) <- "double"
+    .Call("gpmi_R_se_cov", X, Y, phi[[1]], as.double(phi[[2]]))
+  }
   # R/ode_gp.R:1-32 (mn/Kn) and R/ode_gp_library.R:4-33 (condMean/condVar): both name pairs
   .cond <- function(tn, Xn, phi_n, sigma_n, kinds, joint) {
     jit <- if (joint) 1e-6 else 0
@@ -64,8 +67,16 @@ rbf_cov_chol <- function(x1, l_) .Call("gpmi_R_rbf_cov_chol", as.double(x1), l_)
 approx_L <- function(l, lp, Ls, dLdls) .Call("gpmi_R_approx_L", l, as.double(lp), Ls, dLdls)
 approx_Lz <- function(l, lp, Ls, dLdls, z) .Call("gpmi_R_approx_Lz", l, as.double(lp), Ls, dLdls, as.double(z))
 approx_Lz_grad <- function(l, lp, Ls, dLdls, z) .Call("gpmi_R_approx_Lz_grad", l, as.double(lp), Ls, dLdls, as.double(z))
-gp_interp_build <- function(x, lp) invisible(.Call("gpmi_R_interp_build", as.double(x), as.double(lp)))
-gp_interp_Lz <- function(l, z) .Call("gpmi_R_approx_Lz", l, numeric(0), NULL, NULL, as.double(z))
+.gpmi_interp_n <- NULL   # order of the device-resident table
+gp_interp_build <- function(x, lp) {
+  .Call("gpmi_R_interp_build", as.double(x), as.double(lp))
+  .gpmi_interp_n <<- length(x)
+  invisible(NULL)
+}
+gp_interp_Lz <- function(l, z) {
+  stopifnot(!is.null(.gpmi_interp_n), length(z) == .gpmi_interp_n)
+  .Call("gpmi_R_approx_Lz", l, numeric(0), NULL, NULL, as.double(z))
+}
 
 # models/fit_hyperparameters.stan:18-32 as plain functions
 gp_log_marginal <- function(X, y, alpha, rho, sigma, jitter = 0)
@@ -76,12 +87,16 @@ gp_log_marginal_grad <- function(X, y, alpha, rho, sigma, jitter = 0)
   .Call("gpmi_R_logml_grad", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)
 
 # the same for several chains' (alpha, rho, sigma) at once (rstan: chains = 4), concurrently on the GPU
-gp_log_marginal_grad_chains <- function(X, y, alpha, rho, sigma, jitter = 0)
-  .Call("gpmi_R_logml_grad_grid", as.matrix(X), as.double(y), as.double(alpha), as.double(rho), as.double(sigma), jitter)
+gp_log_marginal_grad_chains <- function(X, y, alpha, rho, sigma, jitter = 0) {
+  G <- max(length(alpha), length(rho), length(sigma))   # R recycling: gp_log_marginal_grad_chains(X, y, 1, rho_vec, 0.1)
+  .Call("gpmi_R_logml_grad_grid", as.matrix(X), as.double(y), rep_len(as.double(alpha), G), rep_len(as.double(rho), G),
+        rep_len(as.double(sigma), G), jitter)
+}
 
 gp_log_marginal_grid <- function(X, y, alpha, rho_vec, sigma_vec, jitter = 0) {
   g <- expand.grid(rho = rho_vec, sigma = sigma_vec)
-  r <- .Call("gpmi_R_logml_grid", as.matrix(X), as.double(y), rep(alpha, nrow(g)), g$rho, g$sigma, jitter)
+  r <- .Call("gpmi_R_logml_grid", as.matrix(X), as.double(y), rep_len(as.double(alpha), nrow(g)), as.double(g$rho),
+             as.double(g$sigma), jitter)
   matrix(r[[1]][1, ], nrow = length(rho_vec), ncol = length(sigma_vec))
 }
 
@@ -100,7 +115,7 @@ create_p_dotXnS <- function(Xn_list, mn, Kn, theta, max_steps = 256L) {
   h <- .Call("gpmi_R_seq_create", as.matrix(X), as.double(mn), as.matrix(Kn), theta[[1]], as.double(theta[[2]]),
              1e-6, as.integer(max_steps))
   p_dotXnS <- function(xs_vec) {
-    r <- .Call("gpmi_R_seq_step", h, as.double(xs_vec))
+    r <- .Call("gpmi_R_seq_step", h, as.double(xs_vec), ncol(X))
     dot_xs <- rnorm(1, r[1], r[2])
     .Call("gpmi_R_seq_commit", h, dot_xs)
     list(mu = r[1], sigma = r[2], dot_xs = dot_xs)

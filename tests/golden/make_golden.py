@@ -16,7 +16,9 @@ Two sources, both data only (no reference source text is stored):
    `makeK` (eta2 exp(-(x1-x2)^2 / l2): alpha^2 = eta2, rho^2 = l2 / 2) at N = 1000, the data block
    Kdd, the posterior mean m = Ksd Kdd^-1 f (numpy.linalg.solve, i.e. LAPACK dgesv -- what base-R
    solve() is) and strided samples of Kss and of the posterior covariance Kt.  An SE build at 40x
-   the gp_derivs.py size and a noise-free (sigma2 = 0) posterior.
+   the gp_derivs.py size and a noise-free (sigma2 = 0) posterior.  Since round 3 also the factor the cell
+   computes, L = numpy.linalg.cholesky(Kt + 1e-10 I) (:42, :84; the only Cholesky the reference can execute
+   here): its diagonal, three rows, sum log diag and cond(Kt + 1e-10 I) = 2.7e9 / 2.5e12.
 3. kat.json -- closed-form known-answer tests for the marginal-likelihood path
    (models/fit_hyperparameters.stan:18-32), computed with LAPACK (scipy
    dpotrf/dtrtrs) and confirmed with mpmath at 50 digits.  The reference has no
@@ -113,6 +115,16 @@ def gen_ch2():
             "Kss_sample": Kss[np.ix_(ri, ci)].tolist(),
             "Kt_sample": Kt[np.ix_(ri, ci)].tolist(),
             "Kt_diag": np.diag(Kt).tolist(),
+            # the ONLY Cholesky factor the reference itself computes here: ch2.py:42 / :84,
+            # L = numpy.linalg.cholesky(Kt + 1e-10 I) (LAPACK dpotrf) -- its diagonal, three rows, the
+            # log-determinant half and the condition number of the factored matrix (the forward error
+            # bound of any backward-stable Cholesky is cond * eps: the tests derive their tolerance from it)
+            "L_jitter": 1e-10,
+            "L_diag": np.diag(np.asarray(ns["L"])).tolist(),
+            "L_sum_log_diag": float(np.log(np.diag(np.asarray(ns["L"]))).sum()),
+            "L_rows_idx": [1, N // 2, N - 1],
+            "L_rows": np.asarray(ns["L"])[[1, N // 2, N - 1], :].tolist(),
+            "L_cond": float((lambda ev: ev[-1] / ev[0])(np.linalg.eigvalsh(Kt + 1e-10 * np.eye(N)))),
         })
         print("ch2 cell: N =", N, "eta2 =", ns["eta2"], "sigma2 =", ns["sigma2"], "m[500] =", repr(float(ns["m"][500])))
     with open(os.path.join(HERE, "ch2.json"), "w") as f:

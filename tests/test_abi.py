@@ -104,3 +104,39 @@ def test_null_context_is_an_error_not_a_crash():
     h = _lib.load()
     assert h.gpmi_sync(None) == -1
     assert b"NULL" in h.gpmi_last_error()
+
+
+def test_r_shim_parses_and_matches_the_r_wrappers():
+    """r/gpmi_shim.c is what `.Call` binds (it replaces covariance.cpp:6-9's Rcpp export); there is no R in the
+    image, so it is parsed and type-checked by gcc against tests/r_api/ -- declarations of the R API it uses,
+    nothing of R's behaviour -- and every .Call("name", ...) of r/gpmi.R is matched, by name and number of
+    arguments, to a `SEXP name(SEXP, ...)` of the shim."""
+    shim = os.path.join(ROOT, "r", "gpmi_shim.c")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                        "-I" + os.path.join(ROOT, "tests", "r_api"), "-I" + os.path.join(ROOT, "include"), shim],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = open(shim).read()
+    defs = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
+            for m in re.finditer(r"^SEXP (gpmi_R_\w+)\(([^)]*)\)", src, flags=re.M)}
+    assert len(defs) >= 19
+    rsrc = open(os.path.join(ROOT, "r", "gpmi.R")).read()
+    calls = []
+    for m in re.finditer(r'\.Call\("(gpmi_R_\w+)"', rsrc):
+        # count top-level commas of the call's argument list
+        i = m.end(); depth = 1; commas = 0
+        while depth:
+            ch = rsrc[i]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            commas += (ch == "," and depth == 1)
+            i += 1
+        calls.append((m.group(1), commas))
+    assert len(calls) >= 19
+    for name, nargs in calls:
+        assert name in defs, name
+        assert defs[name] == nargs, (name, defs[name], nargs)
+    # every ABI function the shim calls is declared in include/gpmi.h
+    declared = set(_header_functions())
+    used = set(re.findall(r"\b(gpmi_(?!R_)[a-z_A-Z0-9]+)\s*\(", src)) - {"gpmi_ctx", "gpmi_seq"}
+    assert used <= declared, used - declared

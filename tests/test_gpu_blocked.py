@@ -276,3 +276,47 @@ def test_adaptive_outer_blocks_at_their_thresholds_vs_lapack(ctx, orc, n):
     got = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     print("n=%d: rel err vs LAPACK %.2e" % (n, abs(got - want) / abs(want)))
     assert abs(got - want) <= 1e-10 * abs(want)
+
+
+def test_potrf_vs_the_factor_the_reference_computes(ctx, orc, golden):
+    """gpmi_potrf against the reference's own executed Cholesky (ch2.py:42 / :84, numpy.linalg.cholesky of
+    Kt + 1e-10 I at N = 1000; fixture tests/golden/ch2.json): 8 panels of the blocked code, cond 2.7e9 / 2.5e12.
+    Tolerance cond * eps (forward error bound of a backward-stable Cholesky), as in the oracle's CPU test."""
+    import math
+    eps = np.finfo(float).eps
+    for cell in golden["ch2"]["cells"]:
+        N = cell["N"]; alpha = math.sqrt(cell["eta2"]); rho = math.sqrt(cell["l2"] / 2.0)
+        xs = np.linspace(0.0, 1.0, N); xd = np.array(cell["xd"]); f = np.array(cell["f"])
+        _, Kn = orc.gp_condition(orc.QQ(xd, xd, alpha, rho), orc.QQ(xs, xd, alpha, rho), orc.QQ(xs, xs, alpha, rho), f,
+                                 cell["sigma2"], 0.0)
+        L = ctx.potrf(Kn + cell["L_jitter"] * np.eye(N))
+        tol = cell["L_cond"] * eps
+        d = np.diag(L); dref = np.array(cell["L_diag"])
+        rows = np.array(cell["L_rows"]); idx = cell["L_rows_idx"]
+        e_diag = np.max(np.abs(d - dref) / dref); e_rows = np.max(np.abs(L[idx, :] - rows)) / np.max(np.abs(rows))
+        e_sld = abs(np.log(d).sum() - cell["L_sum_log_diag"])
+        print("ch2 N=%d cond %.1e on the GPU: diag rel %.2e, rows rel %.2e, sum log diag abs %.2e (tolerance %.1e)"
+              % (N, cell["L_cond"], e_diag, e_rows, e_sld, tol))
+        assert e_diag <= tol and e_rows <= tol and e_sld <= tol * math.sqrt(N)
+
+
+@pytest.mark.parametrize("n,m", [(1801, 1300), (1337, 3701)])
+def test_sample_derivs_posterior_factored_at_an_odd_offset(ctx, orc, n, m):
+    """sample_derivs_core factors the Schur complement IN PLACE at W + n + n ld: with odd n the blocked factorisation
+    (fused SYRK, quadrant tiles with 16-B loads, sub-tiled diagonal blocks) gets a base pointer that is 8- but not
+    16-byte aligned; m = 3701 also reaches the adaptive outer-block widths (256 -> 128).  Against LU-solve moments and
+    numpy's Cholesky, as in the aligned case."""
+    rng = np.random.default_rng(n)
+    t = np.sort(rng.uniform(0, n / 10.0, n)); tis = np.sort(rng.uniform(0, n / 10.0, m))
+    yy = np.sin(t) + 0.1 * rng.standard_normal(n)
+    l, a, sy = 0.9, 1.3, 0.1
+    z = rng.standard_normal(m)
+    draw, mu = ctx.sample_derivs(t, tis, yy, l, a, sy, 1e-6, z)
+    K = orc.deriv_cov("QQ", t, t, a, l) + sy * sy * np.eye(n)
+    Ks = orc.deriv_cov("RQ", tis, t, a, l); Kss = orc.deriv_cov("RR", tis, tis, a, l)
+    mu_ref = Ks @ np.linalg.solve(K, yy)
+    cov_ref = Kss - Ks @ np.linalg.solve(K, Ks.T) + 1e-6 * np.eye(m)
+    draw_ref = mu_ref + np.linalg.cholesky(0.5 * (cov_ref + cov_ref.T)) @ z
+    e_mu = np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)); e_d = np.max(np.abs(draw - draw_ref)) / np.max(np.abs(draw_ref))
+    print("sample_derivs n=%d m=%d (odd offset): mu rel %.2e, draw rel %.2e" % (n, m, e_mu, e_d))
+    assert e_mu <= RTOL and e_d <= 1e-7

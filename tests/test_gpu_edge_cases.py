@@ -129,15 +129,15 @@ def test_options_do_not_change_results_beyond_rounding(ctx, orc):
     X, y = orc.synth(900, 3)
     base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     vals = []
-    for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("lookahead", 1), ("lookahead", 0), ("syrk_order", 1),
-                   ("diag_waves", 5), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 0)):
+    for opt, v in (("nb_outer", 128), ("nb_outer", 512), ("ksplit", 0), ("stagger", 0), ("se_nt", 0), ("nb_adapt", 0),
+                   ("fuse_diag", 0), ("fuse_diag", 3), ("block_recursive", 0), ("small_m", 1024)):
         ctx.set_option(opt, v)
         try:
             vals.append(ctx.logml(X, y, 1.0, [0.3], 0.1)[0])
         finally:
-            ctx.set_option("nb_outer", 0); ctx.set_option("lookahead", -1); ctx.set_option("syrk_order", 0)
-            ctx.set_option("diag_waves", 4); ctx.set_option("ksplit", 1); ctx.set_option("stagger", (2 << 16) | 4)
-            ctx.set_option("se_nt", 1); ctx.set_option("nb_adapt", 1)
+            ctx.set_option("nb_outer", 0); ctx.set_option("ksplit", 1); ctx.set_option("stagger", (2 << 16) | 4)
+            ctx.set_option("se_nt", 1); ctx.set_option("nb_adapt", 1); ctx.set_option("fuse_diag", 15)
+            ctx.set_option("block_recursive", 1); ctx.set_option("small_m", 160)
     assert all(abs(v - base) <= 1e-10 * abs(base) for v in vals), (base, vals)
 
 
@@ -202,3 +202,51 @@ def test_fused_diagonal_modes_agree(ctx, orc, n, nbo):
         assert e.value.order == k + 1
     finally:
         ctx.set_option("nb_outer", 0); ctx.set_option("fuse_diag", 15); ctx.set_option("block_recursive", 1)
+
+
+def test_far_and_infinite_points_have_zero_covariance(ctx):
+    """exp(-inf) = 0 in R and Stan: a point whose squared scaled distance overflows, or with an infinite coordinate, is
+    infinitely far away (covariance exactly 0, its own variance alpha^2), not an error; only a NaN coordinate is NaN."""
+    X = np.array([[0.0], [1.0], [1e200], [np.inf], [2.0]])
+    K = ctx.se_cov(X, None, 1.5, [1e-3], diag_add=0.25)
+    assert np.all(np.isfinite(K[:3, :3])) and np.all(K[2, [0, 1, 4]] == 0.0) and np.all(K[[0, 1, 4], 2] == 0.0)
+    assert np.all(np.diag(K) == 1.5 ** 2 + 0.25)
+    assert np.all(K[3, [0, 1, 2, 4]] == 0.0)                  # the infinite point: exp(-inf) = 0 against every finite one
+    Kr = ctx.se_cov(X[:3], X[[4]], 1.0, [1.0])
+    assert Kr[2, 0] == 0.0 and np.all(np.isfinite(Kr))
+    # ... and the evaluation goes through: the far point decouples (its own 1 x 1 block)
+    y = np.array([0.1, -0.2, 0.3])
+    full = ctx.logml(X[:3], y, 1.0, [0.5], 0.3)[0]
+    parts = ctx.logml(X[:2], y[:2], 1.0, [0.5], 0.3)[0] + ctx.logml(X[2:3], y[2:], 1.0, [0.5], 0.3)[0]
+    assert abs(full - parts) <= 1e-13 * abs(full)
+    Xn = X.copy(); Xn[1, 0] = np.nan
+    assert np.isnan(ctx.se_cov(Xn, None, 1.0, [1.0])[1, 0])
+
+
+def test_create_unwinds_on_every_failing_step_without_leaking(ctx):
+    """gpmi_create acquires a stream, five events, six device buffers and four timing events; when step k fails
+    (GPMI_FAIL_CREATE_AT = k: the test hook makes the k-th acquisition report an allocation failure) everything
+    acquired before it is released again: the free device memory after 20 rounds of failing creates at every step is
+    what it was before, and a normal create still works.  KTimer events of a context are released by gpmi_destroy."""
+    import os
+    import torch
+    import gp_amd
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    try:
+        for _ in range(20):
+            for k in range(1, 18):
+                os.environ["GPMI_FAIL_CREATE_AT"] = str(k)
+                with pytest.raises(gp_amd.GpmiError) as e:
+                    gp_amd.Context(0)
+                assert e.value.code in (-3, -2)
+    finally:
+        os.environ.pop("GPMI_FAIL_CREATE_AT", None)
+    other = gp_amd.Context(0)
+    other.set_option("kernel_timing", 1)
+    X = np.linspace(0, 1, 300).reshape(-1, 1)
+    assert math.isfinite(other.logml(X, np.sin(X[:, 0]), 1.0, [0.3], 0.1)[0])
+    other.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 <= 8 << 20, (free0, free1)   # nothing accumulates (allocator granularity aside)

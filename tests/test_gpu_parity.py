@@ -30,7 +30,8 @@ assert np.array_equal(ctx.probe_mfma(A, B), A @ B)
 for n in (900, 2048):  # 2048: a multiple of the tile size, where the augmented row makes the tile grid a trapezoid
     X, y = synth(n, 3)
     base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
-    for opt, v, back in (("gemm_variant", 0, 3), ("gemm_variant", 1, 3), ("gemm_variant", 2, 3)):
+    for opt, v, back in (("gemm_variant", 0, 3), ("gemm_variant", 1, 3), ("gemm_variant", 2, 3), ("lookahead", 1, 0),
+                         ("syrk_order", 1, 0), ("diag_waves", 5, 4)):
         ctx.set_option(opt, v)
         got = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
         ctx.set_option(opt, back)
@@ -50,8 +51,9 @@ def test_probe_build_fragment_layout_and_variants(ctx):
     import gp_amd
     with pytest.raises(gp_amd.GpmiError):
         ctx.probe_mfma(np.zeros((16, 4)), np.zeros((4, 16)))
-    with pytest.raises(gp_amd.GpmiError):
-        ctx.set_option("gemm_variant", 1)
+    for name in ("gemm_variant", "lookahead", "syrk_order", "diag_waves", "lane_lookahead"):
+        with pytest.raises(gp_amd.GpmiError):
+            ctx.set_option(name, 1)
 
 
 @pytest.mark.parametrize("n,m,D", [(1, 1, 1), (21, 21, 1), (64, 64, 3), (65, 130, 3), (200, 77, 2), (257, 300, 5), (130, 129, 8), (70, 33, 9), (40, 50, 20),

@@ -255,6 +255,37 @@ def test_oracle_vs_reference_ch2_cells(orc, golden):
                              - np.array(cell["Kss_sample"]))) <= tol
 
 
+def _ch2_factored_matrix(orc, cell):
+    """Kt + 1e-10 I of a ch2.py cell, rebuilt from the cell's inputs with the oracle's kernels."""
+    N = cell["N"]; alpha = math.sqrt(cell["eta2"]); rho = math.sqrt(cell["l2"] / 2.0)
+    xs = np.linspace(0.0, 1.0, N); xd = np.array(cell["xd"]); f = np.array(cell["f"])
+    _, Kn = orc.gp_condition(orc.QQ(xd, xd, alpha, rho), orc.QQ(xs, xd, alpha, rho), orc.QQ(xs, xs, alpha, rho), f,
+                             cell["sigma2"], 0.0)
+    return Kn + cell["L_jitter"] * np.eye(N)
+
+
+def test_oracle_cholesky_vs_the_factor_the_reference_computes(orc, golden):
+    """ch2.py:42 / :84, L = numpy.linalg.cholesky(Kt + 1e-10 I) at N = 1000: the only Cholesky factor the
+    reference itself can execute here (LAPACK dpotrf).  cond(Kt + 1e-10 I) = 2.7e9 / 2.5e12 (stored in the
+    fixture), so a backward-stable factorisation of a matrix rebuilt to a few ulp agrees with it to
+    cond * eps relative -- the tolerance used, stated per quantity; achieved: ~2e-8 / ~1e-5 on the diagonal."""
+    eps = np.finfo(float).eps
+    for cell in golden["ch2"]["cells"]:
+        A = _ch2_factored_matrix(orc, cell)
+        tol = cell["L_cond"] * eps
+        for blocked in (False, True):
+            L = orc.cholesky(A, blocked=blocked)
+            d = np.diag(L); dref = np.array(cell["L_diag"])
+            e_diag = np.max(np.abs(d - dref) / dref)
+            rows = np.array(cell["L_rows"]); idx = cell["L_rows_idx"]
+            e_rows = np.max(np.abs(L[idx, :] - rows)) / np.max(np.abs(rows))
+            e_sld = abs(np.log(d).sum() - cell["L_sum_log_diag"])
+            print("ch2 N=%d cond %.1e (%s): diag rel %.2e, rows rel %.2e, sum log diag abs %.2e (tolerance %.1e)"
+                  % (cell["N"], cell["L_cond"], "blocked" if blocked else "unblocked", e_diag, e_rows, e_sld, tol))
+            assert e_diag <= tol and e_rows <= tol
+            assert e_sld <= tol * math.sqrt(cell["N"])   # N relative errors of size <= tol, added in quadrature
+
+
 def test_approx_Lz_grad_is_the_derivative_of_approx_Lz(orc):
     """models/cubic_interpolated_gp.hpp:6-32,62-72: the `var` overload gives output i the partial
     (dvdl z)(i) with respect to l.  No reference output exists (Stan is absent): the restated dvdl is
