@@ -162,11 +162,18 @@ static int full_mask_stream(gpmi_ctx *c, hipStream_t *out)
 #endif
 
 // up to 4 dedicated streams that are pairwise concurrent (one per pipe)
-static int calibrate_streams(gpmi_ctx *c)
+// want: concurrent streams the caller can use (lanes, at most 4).  The search is resumed when a later call wants
+// more than an earlier one found: which hardware queue a new stream lands on depends on the streams that exist at
+// that moment (the runtime deals its few hardware queues round-robin), so a calibration run next to ONE lane context
+// may see only two distinct pipes where one next to three finds four -- interp_build / grids then ran lanes 2 and 3
+// on the streams of lanes 0 and 1, i.e. serialised behind them (tools/interp_build_bench.py: 4 lanes == 2 lanes).
+static int calibrate_streams(gpmi_ctx *c, int want = 4)
 {
-    if (c->nq > 0) return 0;
-    int nq = 0, rc;
-    for (int i = 0; i < 10 && nq < 4; ++i) {
+    if (want > 4) want = 4;
+    if (c->nq >= want || c->cal_want >= want) return 0;
+    c->cal_want = want;
+    int nq = c->nq, rc;
+    for (int i = 0; i < 10 && nq < want; ++i) {
         hipStream_t cand;
 #ifdef GPMI_PROBES
         const char *kind = getenv("GPMI_CAL_KIND");  // experiment: 1 = dedicated (CU-mask API) queues
@@ -193,7 +200,7 @@ static int calibrate_streams(gpmi_ctx *c)
 int gpmi_lookahead_streams(gpmi_ctx *c)
 {
     if (c->calibrate && c->nq == 0) {
-        int rc = calibrate_streams(c);
+        int rc = calibrate_streams(c, 2);
         if (rc) return rc;
     }
     if (c->nq >= 2) return 0;
@@ -501,13 +508,13 @@ extern "C" int gpmi_reserve(gpmi_ctx *c, int n_max)
     int rc = reserve_ws(c, n_max + 1, n_max + 1);
     if (rc) return rc;
     // also the grid lanes (contexts, streams, workspaces), so that no allocation happens later
-    // inside a grid call: up to 5 lanes are used in auto mode
-    const int lanes = c->grid_lanes > 0 ? c->grid_lanes : 5;
+    // inside a grid call: up to 4 lanes are used in auto mode
+    const int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
     for (int l = 1; l < lanes && l <= 7; ++l) {
         if (!c->lane[l - 1] && (rc = gpmi_create(&c->lane[l - 1], c->device))) return rc;
         if ((rc = reserve_ws(c->lane[l - 1], n_max + 1, n_max + 1))) return rc;
     }
-    if (lanes > 1 && c->calibrate && (rc = calibrate_streams(c))) return rc;
+    if (lanes > 1 && c->calibrate && (rc = calibrate_streams(c, lanes))) return rc;
     return 0;
 }
 
@@ -804,7 +811,7 @@ static int lanes_prepare(gpmi_ctx *c, int lanes)
         lc->calibrate = 0;                  // a lane never probes for streams of its own
     }
     if (lanes > 1 && c->calibrate) {
-        int rc = calibrate_streams(c);
+        int rc = calibrate_streams(c, lanes);
         if (rc) return rc;
     }
     return 0;
@@ -820,7 +827,7 @@ static void lanes_fork(gpmi_ctx *c, int lanes, hipStream_t caller)
     (void)hipEventRecord(c->evFork, caller);
     for (int l = 0; l < lanes; ++l) {
         gpmi_ctx *lc = l ? c->lane[l - 1] : c;
-        lc->stream = useq ? c->qstream[l % c->nq] : (l ? lc->own_stream : caller);
+        lc->stream = (useq && l < c->nq) ? c->qstream[l] : (l ? lc->own_stream : caller);
         if (lc->stream != caller) (void)hipStreamWaitEvent(lc->stream, c->evFork, 0);
     }
 }
@@ -942,8 +949,9 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
     // Independent points fan out over `lanes` internal contexts (own workspaces and streams):
     // while one point is in its latency-bound panel phase or in the tail of a trailing update,
     // another point's bulk update fills the chip.  Lanes fork from / join into the caller's stream.
-    // auto: 4 lanes, or 3 / 5 when that splits the grid evenly (all points cost the same)
-    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : (G % 5 == 0 ? 5 : 4)));
+    // auto: 4 lanes (one per calibrated dispatch stream), or 3 when that splits the grid evenly and 4 does not; a fifth
+    // lane has no pipe of its own: G = 10 at N = 4096 / 8192 took 0.85 / 3.89 ms per point on 5 lanes, 0.71 / 3.58 on 4
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : 4));
     if (lanes > 8) lanes = 8;
     if (lanes > G) lanes = G;
     int rc = lanes_prepare(c, lanes);
@@ -1087,7 +1095,7 @@ extern "C" int gpmi_joint_logml_grid_dev(gpmi_ctx *c, const double *dt, int n, c
     if (n <= 0 || !dt || !dyy || !alpha || !l || !sigma || !d_out3 || !d_info) return gpmi_fail(GPMI_EARG, "bad argument");
     for (int g = 0; g < G; ++g)
         if (!(l[g] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
-    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : (G % 5 == 0 ? 5 : 4)));
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : 4));
     if (lanes > 8) lanes = 8;
     if (lanes > G) lanes = G;
     int rc = lanes_prepare(c, lanes);
@@ -1472,7 +1480,9 @@ __global__ __launch_bounds__(256) void k_upper_mv_sum(const double *__restrict__
 
 // per 64 x 64 tile of the lower triangle: sums of w g kse, w g kse (x_id - x_jd)^2 (d < D), [i == j] g
 // with g = (a_i a_j + Wij) / 2 (W holds -K^-1), w = 2 off the diagonal (symmetry), 1 on it
-constexpr int GRAD_NS = 2 + GPMI_MAXD;
+constexpr int GRAD_NS = 2 + GPMI_MAXD;           // slots per tile of the D <= 8 kernel
+constexpr int GRAD_NS_MAX = 2 + GPMI_MAXD_BIG;   // ... and the most the generic one writes (D = 64)
+static inline int grad_ns(int D) { return 2 + ((D + 7) / 8) * 8; }
 __global__ __launch_bounds__(256) void k_grad_partial(const double *__restrict__ X, int n, int ldx, SeParams p,
                                                       const double *__restrict__ a, const double *__restrict__ W,
                                                       size_t ld, double *__restrict__ part)
@@ -1522,13 +1532,100 @@ __global__ __launch_bounds__(256) void k_grad_partial(const double *__restrict__
     }
 }
 
+// The same contraction for ANY D <= GPMI_MAXD_BIG (QQard takes any D, R/kernels.R:11-19): 64 x 64 tile of the lower
+// triangle, thread = one row x 16 columns.  The coordinates of the tile's rows and columns are staged in LDS in
+// chunks of 16 dimensions; pass 1 accumulates the scaled squared distance of the thread's 16 pairs over all D and
+// turns it into c_q = w g kse (16 registers), pass 2 walks the dimensions again and reduces sum_q c_q (x_id - x_jd)^2
+// over the workgroup, one fixed-shape tree per dimension (deterministic).  Slots per tile: ns = 2 + roundup(D, 8):
+// [0] sum c, [1 + d] per dimension, [ns - 1] the diagonal term -- the layout of k_grad_partial for D <= 8.
+// O(N^2 D) next to the O(N^3) of K^-1: 64 trees per tile at D = 64 are noise.
+__global__ __launch_bounds__(256) void k_grad_partial_big(const double *__restrict__ X, int n, int ldx, SeParams p,
+                                                          const double *__restrict__ a, const double *__restrict__ W,
+                                                          size_t ld, double *__restrict__ part, int ns)
+{
+    __shared__ double sx[16][64], sy[16][64], red[256];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = ti * 64 + lane, j0 = tj * 64 + grp * 16;
+    const int ic = i < n ? i : n - 1;
+    double e[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e[q] = 0.0;
+    auto stage = [&](int d0, int dc) {
+        __syncthreads();
+        for (int k = grp; k < 2 * dc; k += 4) {   // wave-uniform: operand and dimension
+            const int dd = k >> 1;
+            if (k & 1) {
+                const int j = tj * 64 + lane;
+                sy[dd][lane] = X[(size_t)(j < n ? j : n - 1) + (size_t)(d0 + dd) * ldx];
+            } else {
+                sx[dd][lane] = X[(size_t)ic + (size_t)(d0 + dd) * ldx];
+            }
+        }
+        __syncthreads();
+    };
+    for (int d0 = 0; d0 < p.D; d0 += 16) {
+        const int dc = p.D - d0 < 16 ? p.D - d0 : 16;
+        stage(d0, dc);
+        for (int dd = 0; dd < dc; ++dd) {
+            const double xi = sx[dd][lane], ie2 = p.inv_ell[d0 + dd] * p.inv_ell[d0 + dd];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double r = xi - sy[dd][grp * 16 + q];
+                e[q] += r * r * ie2;
+            }
+        }
+    }
+    double c0 = 0.0, cdiag = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {   // e[q] becomes c_q
+        const int j = j0 + q;
+        double cq = 0.0;
+        if (i < n && j < n && j <= i) {
+            const double g = 0.5 * (a[i] * a[j] + W[(size_t)i + (size_t)j * ld]);
+            cq = ((i == j) ? 1.0 : 2.0) * g * (p.a2 * exp(-0.5 * e[q]));
+            if (i == j) cdiag += g;
+        }
+        e[q] = cq;
+        c0 += cq;
+    }
+    const size_t slot = ((size_t)ti * (ti + 1) / 2 + tj) * (size_t)ns;
+    auto reduce_to = [&](double v, size_t dst) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[dst] = red[0];
+        __syncthreads();
+    };
+    reduce_to(c0, slot);
+    reduce_to(cdiag, slot + (size_t)ns - 1);
+    for (int d0 = 0; d0 < p.D; d0 += 16) {
+        const int dc = p.D - d0 < 16 ? p.D - d0 : 16;
+        stage(d0, dc);
+        for (int dd = 0; dd < dc; ++dd) {
+            const double xi = sx[dd][lane];
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double r = xi - sy[dd][grp * 16 + q];
+                v += e[q] * (r * r);
+            }
+            reduce_to(v, slot + 1 + (size_t)(d0 + dd));
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ part, size_t ntiles,
-                                                     double *__restrict__ sums)
+                                                     double *__restrict__ sums, int ns)
 {
     __shared__ double red[1024];
-    for (int s = 0; s < GRAD_NS; ++s) {
+    for (int s = 0; s < ns; ++s) {
         double acc = 0.0;
-        for (size_t t = threadIdx.x; t < ntiles; t += 1024) acc += part[t * GRAD_NS + s];
+        for (size_t t = threadIdx.x; t < ntiles; t += 1024) acc += part[t * (size_t)ns + s];
         red[threadIdx.x] = acc;
         __syncthreads();
         for (int h = 512; h > 0; h >>= 1) {
@@ -1542,8 +1639,9 @@ __global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ 
 }  // namespace
 
 // every buffer logml_grad_core(c, ., n, ...) uses, at its final size
-static int logml_grad_reserve(gpmi_ctx *c, int n)
+static int logml_grad_reserve(gpmi_ctx *c, int n, int D)
 {
+    const int ns = grad_ns(D);
     int rc;
     if ((rc = reserve_ws(c, n + 1, n))) return rc;
     const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
@@ -1552,25 +1650,26 @@ static int logml_grad_reserve(gpmi_ctx *c, int n)
     const int nchunk = (n + UMV_COLS - 1) / UMV_COLS;
     double *b;
     if ((rc = stage_buf(c, 2, ldu * (size_t)(n + 1) * sizeof(double), &b))) return rc;
-    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS + ntiles * GRAD_NS + (size_t)nchunk * n) * sizeof(double), &b))) return rc;
+    if ((rc = stage_buf(c, 3, (2 * (size_t)n + GRAD_NS_MAX + ntiles * ns + (size_t)nchunk * n) * sizeof(double), &b))) return rc;
     return scratch_buf(c, (size_t)npan * GPMI_FPACK * sizeof(double), &b);
 }
 
 // Device part of one value + gradient evaluation, enqueued on c->stream without synchronisation:
-// d_res[0..2] = (logml, sum log L_ii, z'z), d_res[3 .. 3 + GRAD_NS) = the contraction sums, *d_info = status
-constexpr int GRAD_RES = 3 + GRAD_NS;
+// d_res[0..2] = (logml, sum log L_ii, z'z), d_res[3 .. 3 + grad_ns(D)) = the contraction sums, *d_info = status
+constexpr int GRAD_RES = 3 + GRAD_NS_MAX;
 static int logml_grad_core(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
                            double *d_res, int *d_info)
 {
     int rc;
-    if ((rc = logml_grad_reserve(c, n))) return rc;
+    if ((rc = logml_grad_reserve(c, n, p.D))) return rc;
+    const int ns = grad_ns(p.D);
     const int M = n + 1;
     const size_t ld = (size_t)c->ld;
     const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
     const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
     const int nchunk = (n + UMV_COLS - 1) / UMV_COLS;
     double *U = c->stage[2], *vec = c->stage[3], *Fall = c->scratch;
-    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS, *mvpart = part + ntiles * GRAD_NS;
+    double *zv = vec, *av = vec + n, *sums = vec + 2 * (size_t)n, *part = sums + GRAD_NS_MAX, *mvpart = part + ntiles * ns;
     hipStream_t s = c->stream;
     // factorisation with the augmented row, all panel factors kept
     HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
@@ -1587,8 +1686,11 @@ static int logml_grad_core(gpmi_ctx *c, const double *dX, int n, int ldx, const 
     // W(lower) = -U U^T = -K^-1
     HIPCHK(hipMemsetAsync(c->W, 0, ld * (size_t)n * sizeof(double), s));
     launch_syrk_uut(c, s, U, ldu, c->W, ld, n);
-    hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, ldx, p, av, c->W, ld, part);
-    hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, d_res + 3);
+    if (p.D <= GPMI_MAXD)   // register-resident coordinates
+        hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, ldx, p, av, c->W, ld, part);
+    else                    // any D: LDS-staged coordinates, one pass for the distances and one per dimension
+        hipLaunchKernelGGL(k_grad_partial_big, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, ldx, p, av, c->W, ld, part, ns);
+    hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, d_res + 3, ns);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1604,7 +1706,7 @@ static void logml_grad_finish(const double *hs, int D, double alpha, const doubl
     } else {
         for (int d = 0; d < D; ++d) grad[1 + d] = hs[1 + d] / (ell[d] * ell[d] * ell[d]);
     }
-    grad[1 + n_ell] = 2.0 * sigma * hs[1 + GPMI_MAXD];
+    grad[1 + n_ell] = 2.0 * sigma * hs[grad_ns(D) - 1];
 }
 
 extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y,
@@ -1613,13 +1715,12 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
 {
     ENTER(c);
     if (n <= 0 || !X || !y || !out3 || !grad || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
-    if (D > GPMI_MAXD) return gpmi_fail(GPMI_EARG, "gradient supports D <= %d", GPMI_MAXD);
     SeParams p;
     int rc;
     if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
     double *dX, *dy, *dres;
     if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
-    if ((rc = logml_grad_reserve(c, n))) return rc;
+    if ((rc = logml_grad_reserve(c, n, D))) return rc;
     dres = c->d_fin + 4096;  // second half of the finalize scratch (64 KiB): GRAD_RES doubles
     if ((rc = logml_grad_core(c, dX, n, n, dy, p, sigma * sigma + jitter, dres, c->d_info + 1))) return rc;
     double hr[GRAD_RES];
@@ -1650,7 +1751,6 @@ extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx
     if (G == 0) return 0;
     if (n <= 0 || !X || !y || !alpha || !rho || !sigma || !out3 || !grad || !info || ldx < n || D < 1)
         return gpmi_fail(GPMI_EARG, "bad argument");
-    if (D > GPMI_MAXD) return gpmi_fail(GPMI_EARG, "gradient supports D <= %d", GPMI_MAXD);
     int rc;
     std::vector<SeParams> ps(G);
     for (int g = 0; g < G; ++g)
@@ -1660,7 +1760,7 @@ extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx
     if (lanes > G) lanes = G;
     if ((rc = lanes_prepare(c, lanes))) return rc;
     for (int k = 0; k < lanes; ++k)
-        if ((rc = logml_grad_reserve(k ? c->lane[k - 1] : c, n))) return rc;
+        if ((rc = logml_grad_reserve(k ? c->lane[k - 1] : c, n, D))) return rc;
     double *dX, *dy, *dres;
     if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
     // the root context's scratch also holds its packed panel factors (logml_grad_reserve): the results live behind them

@@ -91,6 +91,7 @@ struct gpmi_ctx {
     // (see calibrate_streams in gpmi_api.hip).
     hipStream_t qstream[4];
     int nq;                  // number of mutually concurrent streams found (0 = not probed yet)
+    int cal_want;            // ... the largest number a calibration run has searched for so far
     int calibrate;           // 1: run grid lanes on qstream[]; 0: on the lanes' plain streams
 };
 

@@ -155,14 +155,15 @@ GPMI_API int gpmi_logml_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int
  * grad[0] = d/dalpha, grad[1 .. n_ell] = d/dell, grad[1 + n_ell] = d/dsigma.  This is what Stan's
  * autodiff computes per leapfrog step for models/fit_hyperparameters.stan:18-32 (the reference has
  * no function of its own for it); 1/2 tr((a a' - K^-1) dK/dtheta) with K^-1 formed on the device.
- * D <= 8.  Same status codes as gpmi_logml (k > 0: not positive definite, grad = NaN). */
+ * Any D the covariance builder takes (<= 64; QQard, R/kernels.R:11-19).  Same status codes as gpmi_logml
+ * (k > 0: not positive definite, grad = NaN). */
 GPMI_API int gpmi_logml_grad(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
                     double alpha, const double *ell, int n_ell, double sigma, double jitter,
                     double *out3, double *grad);
 
 /* Value AND gradient at G independent points (alpha[g], rho[g], sigma[g]), concurrently on the context's lanes: what
  * rstan's default four chains (pendulum_fit.R:140: chains = 4, cores = 4) ask for per leapfrog step.  out3: 3 G;
- * grad: 3 G, (d/dalpha, d/drho, d/dsigma) per point; info: G (non-PD: NaN, the grid continues).  D <= 8. */
+ * grad: 3 G, (d/dalpha, d/drho, d/dsigma) per point; info: G (non-PD: NaN, the grid continues).  D <= 64. */
 GPMI_API int gpmi_logml_grad_grid(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
                                   const double *alpha, const double *rho, const double *sigma, int G, double jitter,
                                   double *out3, double *grad, int *info);

@@ -9,11 +9,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,D", [(7, 1), (50, 1), (129, 2), (300, 3), (700, 2)])
+@pytest.mark.parametrize("n,D", [(7, 1), (50, 1), (129, 2), (300, 3), (700, 2), (200, 9), (333, 16), (150, 33), (70, 64)])
 def test_grad_vs_oracle(ctx, orc, n, D):
     rng = np.random.default_rng(100 + n)
     X = rng.random((n, D)); y = np.sin(3 * X.sum(axis=1)) + 0.1 * rng.standard_normal(n)
-    a, r, s = 1.2, 0.4, 0.15
+    a, r, s = 1.2, 0.4 * math.sqrt(D), 0.15    # (D > 8: the LDS-staged contraction, gpmi_api.hip k_grad_partial_big)
     out, g = ctx.logml_grad(X, y, a, [r], s)
     want_out, want_g, info = orc.logml_grad(X, y, a, r, s)
     assert info == 0
@@ -39,13 +39,31 @@ def test_grad_ard_vs_central_differences(ctx):
     np.testing.assert_allclose(g, fd, rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("D", [9, 20])
+def test_grad_ard_many_dimensions_vs_central_differences(ctx, D):
+    rng = np.random.default_rng(D)
+    n = 300
+    X = rng.random((n, D)); y = np.cos(2 * X[:, 0]) * X[:, 1] + X[:, D - 1] + 0.05 * rng.standard_normal(n)
+    a, ell, s = 0.9, 0.8 + 1.5 * rng.random(D), 0.2
+    _, g = ctx.logml_grad(X, y, a, ell, s)
+    assert g.shape == (D + 2,)
+    h = 1e-5
+    f = lambda a_, e_, s_: ctx.logml(X, y, a_, e_, s_)[0]
+    fd = [(f(a + h, ell, s) - f(a - h, ell, s)) / (2 * h)]
+    for d in range(D):
+        e = np.zeros(D); e[d] = h
+        fd.append((f(a, ell + e, s) - f(a, ell - e, s)) / (2 * h))
+    fd.append((f(a, ell, s + h) - f(a, ell, s - h)) / (2 * h))
+    np.testing.assert_allclose(g, fd, rtol=5e-6, atol=2e-6)
+
+
 def test_grad_not_positive_definite_and_bad_arguments(ctx):
     import gp_amd
     X = np.zeros((20, 1)); y = np.ones(20)  # identical points, no noise: singular
     with pytest.raises(gp_amd.NotPositiveDefinite):
         ctx.logml_grad(X, y, 1.0, [0.5], 0.0)
     with pytest.raises(gp_amd.GpmiError):
-        ctx.logml_grad(np.zeros((5, 9)), np.zeros(5), 1.0, [0.5], 0.1)  # D > 8
+        ctx.logml_grad(np.zeros((5, 65)), np.zeros(5), 1.0, [0.5], 0.1)  # D > 64
     out, g = ctx.logml_grad(np.linspace(0, 1, 30), np.ones(30), 1.0, [0.3], 0.1)  # healthy afterwards
     assert math.isfinite(out[0]) and np.all(np.isfinite(g))
 
