@@ -53,12 +53,15 @@ def parse_args(argv=None):
                          "rho x sigma grid at N=8192 sharded over the ranks (strong scaling); c5: derivative "
                          "joint [y, y'] covariance, N=8192 (matrix order 16384)")
     ap.add_argument("--grid-lanes", type=int, default=0, help="concurrent evaluations per GPU (0 = auto)")
+    ap.add_argument("--syrk-order", type=int, default=-1, choices=[-1, 0, 2],
+                    help="tile walk of the multi-round trailing updates: 0 row-major, 2 XCD-partitioned bands, -1 library default")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on cuda:0")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / sharding / gather only (gloo, no GPU): the CPU test of the N>1 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the c4 strong-scaling sub-record")
+    ap.add_argument("--no-c1", action="store_true", help="skip the c1 / small-N sub-record (PMC passes: keeps per-kernel averages clean)")
     return ap.parse_args(argv)
 
 
@@ -168,6 +171,50 @@ def c4_grid():
     return R.ravel(), S.ravel()
 
 
+def c1_record(ctx, dev, skip_cpu):
+    """BASELINE config c1 (N = 256, D = 1: x = linspace(0, 10, 256), y = sin(x), alpha = 1, rho = 1, sigma = 0.1 --
+    the reference's plumbing size, R/tests.R / SURVEY KAT K2) and the sizes its drivers really call the path at
+    (N = 21: R/tests.R:5; N = 199: pendulum_fit.R:26-27): latency of ONE host-buffer call (what `.Call` binds),
+    per-evaluation time of a 64-point grid (one launch of the one-workgroup kernels), and the single-threaded
+    oracle timed directly at the same N beside them."""
+    import torch
+    rec = {"workload": "c1 and the reference's own sizes: one host-buffer gpmi_logml call; 64-point (rho x sigma) grid through "
+                       "gpmi_logml_grid_dev (one workgroup per point, one launch)", "sizes": []}
+    ctx.set_stream(None)
+    for n in (21, 199, 256):
+        x = np.linspace(0.0, 10.0, n).reshape(-1, 1); y = np.sin(x[:, 0])
+        ctx.logml(x, y, 1.0, [1.0], 0.1)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            val = ctx.logml(x, y, 1.0, [1.0], 0.1)[0]
+        host_us = 1e6 * (time.perf_counter() - t0) / 200
+        dx = torch.from_numpy(x[:, 0].copy()).to(dev); dy = torch.from_numpy(y).to(dev)
+        G = 64
+        out = torch.zeros((G, 3), dtype=torch.float64, device=dev); info = torch.zeros(G, dtype=torch.int32, device=dev)
+        R, S = c4_grid()
+        best = float("inf")
+        for r in range(6):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ctx.logml_grid_dev(dx.data_ptr(), n, n, 1, dy.data_ptr(), np.ones(G), R * 10.0, S, 0.0, out.data_ptr(), info.data_ptr())
+            ctx.sync()
+            if r:
+                best = min(best, time.perf_counter() - t0)
+        e = {"N": n, "logml": float(val), "host_buffer_call_us": host_us, "grid64_us_per_eval": 1e6 * best / G,
+             "grid64_evals_per_s": G / best, "grid64_results_ok": bool(np.all(info.cpu().numpy() == 0))}
+        if not skip_cpu:
+            from oracle import oracle as orc
+            orc.logml(x, y, 1.0, 1.0, 0.1)
+            t0 = time.perf_counter()
+            reps = 20 if n > 100 else 200
+            for _ in range(reps):
+                want = orc.logml(x, y, 1.0, 1.0, 0.1)[0]
+            e["cpu_oracle_1_thread_us"] = 1e6 * (time.perf_counter() - t0) / reps
+            e["rel_err_vs_oracle"] = abs(val - want) / abs(want)
+        rec["sizes"].append(e)
+    return rec
+
+
 def dry_run(args):
     """The N>1 path without a GPU: same launcher, same rendezvous, same sharding (point g -> rank
     g mod P) and the same all_gather as the c4 sub-record, with a closed-form stand-in for the
@@ -242,6 +289,8 @@ def main():
         ctx.set_option("nb_outer", args.nb_outer)
     if args.grid_lanes:
         ctx.set_option("grid_lanes", args.grid_lanes)
+    if args.syrk_order >= 0:
+        ctx.set_option("syrk_order", args.syrk_order)
     ctx.reserve(2 * n if args.workload == "c5" else n)  # workspaces of every grid lane, outside the timed region
 
     # deterministic synthetic inputs, generated on the host once and
@@ -543,6 +592,8 @@ def main():
             t1 = time.perf_counter()
             ctx.logml(X, y, 1.0, [0.3], 0.1)
             line["ms_per_eval_host_buffer_abi"] = 1e3 * (time.perf_counter() - t1)
+        if world == 1 and args.workload == "c3" and not args.no_c1:
+            line["c1"] = c1_record(ctx, dev, args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline and args.workload == "c3":
             ns = args.cpu_sample_n
             dt, lm_cpu = cpu_baseline(ns, D)

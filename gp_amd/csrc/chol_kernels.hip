@@ -512,6 +512,41 @@ __host__ inline int syrk_grid(int T, int TN, int order)
     return ((ns + 7) / 8) * 8 * ST * ST;
 }
 
+// XCD-partitioned band walk (order 2) of the lower triangle / trapezoid, WITHOUT a padded grid: the valid tiles are
+// enumerated band by band (8 tile rows), inside a band column by column -- 64 consecutive tiles are an 8 x 8 patch --
+// and workgroup b takes canonical tile (b % 8) S + b / 8, S = ceil(ntiles / 8): the workgroups the dispatcher deals to
+// one XCD (observed: b % 8; speed only, any placement is correct) walk ONE contiguous eighth of that order.  The 64
+// tiles resident on an XCD at a time then share 8 row blocks (for a whole band) and 8 column blocks of the panel
+// through that XCD's L2 instead of ~5 + 15 that change every round.  Every XCD gets the same number of tiles, so the
+// launch ends as evenly as the row-major walk; the last partial round of EACH XCD is what the tail split cuts into
+// quadrants, and a thin last tile row (the augmented row) is multiplied as quadrants by its own workgroup.
+__device__ __forceinline__ void syrk_tile_bands(int c, int T, int TN, int &ti, int &tj)
+{
+    for (int r0 = 0;; r0 += 8) {
+        const int R = (T - r0 < 8) ? T - r0 : 8;
+        const int cf = r0 < TN ? r0 : TN;                          // columns left of the band's diagonal block: R tiles each
+        const int dmax = (TN - r0 < R) ? (TN - r0 > 0 ? TN - r0 : 0) : R;  // columns r0 + d of the diagonal block: rows d .. R - 1
+        const int cnt = R * cf + dmax * R - dmax * (dmax - 1) / 2;
+        if (c < cnt || R <= 0) {
+            if (c < R * cf) {
+                tj = c / R;
+                ti = r0 + c - tj * R;
+                return;
+            }
+            c -= R * cf;
+            int d = 0;
+            while (d < dmax - 1 && c >= R - d) {
+                c -= R - d;
+                ++d;
+            }
+            tj = r0 + d;
+            ti = r0 + d + c;
+            return;
+        }
+        c -= cnt;
+    }
+}
+
 // One 128 x 128 output tile (ti, tj); smem is the workgroup's staging buffer (free on entry:
 // every wave has finished reading it).
 template <int MODE>
@@ -1021,6 +1056,34 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
         }
         const int T = (M + GT - 1) / GT;
         const int TN = (N + GT - 1) / GT < T ? (N + GT - 1) / GT : T;
+        if ((order & 0xff) == 2) {  // XCD-partitioned band walk (multi-round launches)
+            const int nt = TN * (TN + 1) / 2 + (T - TN) * TN;
+            const int S = (nt + 7) >> 3;
+            int c, quad = -1;  // quad < 0: the whole tile
+            if (b < 8 * S) {
+                const int s = b >> 3;
+                c = (b & 7) * S + s;
+                if (ks.S > 1 && s >= ks.bfull) quad = 0;  // last partial round of this XCD: quadrant 0 here, 1 .. 3 behind the grid
+            } else {
+                const int e = b - 8 * S, Rx = S - ks.bfull, t = e / 3;
+                quad = 1 + e - 3 * t;
+                c = (t / Rx) * S + ks.bfull + t % Rx;
+            }
+            if (c >= nt) return;
+            syrk_tile_bands(c, T, TN, ti, tj);
+            const bool thin = ti == T - 1 && T > 1 && M - ti * GT <= 64 && K % GK == 0;  // e.g. the augmented row alone
+            if (quad >= 0 || thin) {
+                for (int q = quad >= 0 ? quad : 0; q < (quad >= 0 ? quad + 1 : 4); ++q) {
+                    const int qm = q & 1, qn = (q >> 1) & 1;
+                    const int m0 = ti * GT + qm * 64, n0 = tj * GT + qn * 64;
+                    if ((ti == tj && qn > qm) || m0 >= M || n0 >= N) continue;  // workgroup-uniform
+                    gemm_quad64(&smem[0][0][0][0], A + m0, lda, B + n0, ldb, C + (size_t)m0 + (size_t)n0 * ldc, ldc, K, M - m0,
+                                N - n0, (int)threadIdx.x);
+                    __syncthreads();
+                }
+                return;
+            }
+        } else
         if (ks.S > 1 && b >= ks.bfull) {
             const int q = b - ks.bfull;
             if (!syrk_tile(ks.bfull + (q >> 2), T, TN, order & 0xff, ti, tj)) return;
@@ -1032,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const double *__restrict__ A
                         N - n0, (int)threadIdx.x);
             return;
         }
-        if (!syrk_tile(b, T, TN, order & 0xff, ti, tj)) return;
+        if ((order & 0xff) != 2 && !syrk_tile(b, T, TN, order & 0xff, ti, tj)) return;
         // order bit 8: the panel is UPPER TRIANGULAR (P[i][k] = 0 for k < i, e.g. L^-T): the
         // products of tile (ti, tj), tj <= ti, start at column ti * 128 -- a third of the work of
         // the full update; row-major tile order runs the long tiles first
@@ -2047,7 +2110,7 @@ static void small_lds_attr()
 
 void gpmi_tuning_defaults(gpmi_tuning *t)
 {
-    t->syrk_order = 0;  // (probe build only)
+    t->syrk_order = 2;
     t->stagger = (2 << 16) | 4;
     t->fuse_diag = 15;
     t->diag_waves = 4;
@@ -2162,12 +2225,17 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
     const int T = (M + GT - 1) / GT;
     // N < M: lower trapezoid (block column of a look-ahead update), row-major order only
     const int TNf = (N + GT - 1) / GT, TN = TNf < T ? TNf : T;
+    const int slots = 2 * (ncu > 0 ? ncu : 256);
+    // tile walk: 0 row-major; 2 XCD-partitioned bands (launches of more than one round of tiles: that is where the
+    // operand re-reads that miss the XCD L2s come from); 1 (probe build) the padded 8 x 8 super-tile grid of round 1
+    // Walk 2 is the default for an evaluation that has the chip to itself (N = 16384: L2 hit rate 53 -> 79 %, L2-miss
+    // traffic 1.27 -> 0.65 GB per launch, 27.31 -> 27.07 ms); under the grid lanes, where four launches share every
+    // XCD, its static per-XCD partition loses 1.6 % (23.09 -> 23.45 ms per point) and the row-major walk stays.
+    int syrk_order = (c->tune.syrk_order == 2 && !c->lanes_active && syrk_grid(T, TN, 0) > slots) ? 2 : 0;
 #ifdef GPMI_PROBES
-    const int syrk_order = TN < T ? 0 : c->tune.syrk_order;
-#else
-    const int syrk_order = 0;  // row-major walk of the lower triangle / trapezoid
+    if (c->tune.syrk_order == 1 && TN == T) syrk_order = 1;
 #endif
-    const int ntiles = syrk_grid(T, TN, syrk_order);
+    const int ntiles = syrk_grid(T, TN, syrk_order == 1 ? 1 : 0);
     const int stg = ntiles >= 1024 ? c->tune.stagger : 0;  // only when every CU holds two workgroups for many rounds
 #ifdef GPMI_PROBES
     if (c->tune.gemm_variant == 2) {
@@ -2184,8 +2252,7 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
     // tile (0, 0) is block 0 only in the row-major order
     // only in launches of more than one round of tiles, where workgroup 0's extra 27 us do not
     // lengthen the kernel
-    const int slots = 2 * (ncu > 0 ? ncu : 256);
-    bool fuse = fd && fd->Fp && (c->tune.fuse_diag & 2) && syrk_order == 0 && ntiles > slots;
+    bool fuse = fd && fd->Fp && (c->tune.fuse_diag & 2) && syrk_order != 1 && ntiles > slots;  // tile (0, 0) is block 0 in walks 0 and 2
     // Single-round launches: the next diagonal block rides along as well, sub-tiled like in the in-block products
     // (fused_subtiles_and_diag) -- its 36 sub-tiles and the block's factorisation (~6 + 21 us) run beside the other
     // tiles instead of in a kernel of their own behind the launch (tune.fuse_diag bit 3).
@@ -2199,6 +2266,17 @@ static bool launch_syrk_lower(const gpmi_ctx *c, hipStream_t s, const double *P,
     }
     KSplit ks{};
     int grid = ntiles;
+    if (syrk_order == 2) {
+        // every XCD walks S tiles on its slots / 8 workgroup slots: its last partial round, when thin, runs as quadrants
+        // (quadrant 0 by the tile's own workgroup, 1 .. 3 by workgroups behind the grid)
+        const int S = (ntiles + 7) / 8, per = slots / 8;
+        const int S_full = (S / per) * per, Rx = S - S_full;
+        grid = 8 * S;
+        if (c->tune.ksplit && K % GK == 0 && Rx > 0 && 8 * Rx <= c->tune.ksplit_max) {
+            ks = KSplit{S_full, 4};
+            grid += 3 * 8 * Rx;
+        }
+    } else
     if (c->tune.ksplit && syrk_order == 0 && K % GK == 0) {
         int first = ntiles;  // first tile computed as quadrants
         const int bfull = (ntiles / slots) * slots, R = ntiles - bfull;

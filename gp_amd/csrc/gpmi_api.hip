@@ -393,6 +393,17 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->tune.nb_thr[name[6] == '1' ? 0 : (name[6] == '5' ? 1 : 2)] = value;
         return 0;
     }
+    if (!strcmp(name, "syrk_order")) {   // tile walk of multi-round trailing updates: 0 row-major, 2 XCD-partitioned bands
+#ifdef GPMI_PROBES
+        if (value == 1) {                // (probe build) the padded 8 x 8 super-tile grid of round 1
+            c->tune.syrk_order = 1;
+            return 0;
+        }
+#endif
+        if (value != 0 && value != 2) return gpmi_fail(GPMI_EARG, "syrk_order must be 0 (row-major) or 2 (XCD bands)");
+        c->tune.syrk_order = value;
+        return 0;
+    }
     if (!strcmp(name, "small_n")) {  // one-workgroup marginal likelihood up to this n (0: off, <= 256)
         if (value < 0 || value > 256) return gpmi_fail(GPMI_EARG, "small_n must be 0 .. 256");
         c->tune.small_n = value;
@@ -410,10 +421,6 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
     }
 #ifdef GPMI_PROBES
     // switches of measured-and-rejected variants, kept as A/B material in the probe build only
-    if (!strcmp(name, "syrk_order")) {   // 1: XCD-grouped 8 x 8 super-tile walk of the SYRK triangle
-        c->tune.syrk_order = value != 0;
-        return 0;
-    }
     if (!strcmp(name, "diag_waves")) {   // 5: the 5-wave / 3-barrier diagonal-block kernel of round 1
         if (value != 4 && value != 5) return gpmi_fail(GPMI_EARG, "diag_waves must be 4 or 5");
         c->tune.diag_waves = value;
@@ -828,6 +835,7 @@ static void lanes_fork(gpmi_ctx *c, int lanes, hipStream_t caller)
     for (int l = 0; l < lanes; ++l) {
         gpmi_ctx *lc = l ? c->lane[l - 1] : c;
         lc->stream = (useq && l < c->nq) ? c->qstream[l] : (l ? lc->own_stream : caller);
+        lc->lanes_active = 1;
         if (lc->stream != caller) (void)hipStreamWaitEvent(lc->stream, c->evFork, 0);
     }
 }
@@ -843,6 +851,7 @@ static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
             (void)hipStreamWaitEvent(caller, lc->evJoin, 0);
         }
         lc->stream = l ? lc->own_stream : caller;
+        lc->lanes_active = 0;
     }
 }
 

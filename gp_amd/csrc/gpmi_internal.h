@@ -22,7 +22,7 @@ struct SeParams {            // squared-exponential hyper-parameters, kernel-arg
 // Algorithm switches of one context (gpmi_set_option).  Per context, never process-global: two
 // contexts or two host threads do not change each other's algorithm; grid lanes copy their root's.
 struct gpmi_tuning {
-    int syrk_order;       // (probe build only) 0: row-major triangle, 1: XCD-grouped 8x8 super-tiles
+    int syrk_order;       // tile walk of multi-round trailing updates: 0 row-major, 2 XCD-partitioned bands (1: probe build, padded super-tiles)
     int stagger;          // (mode << 16) | number of s_sleep(127) (~3.5 us each) for the late workgroup of a CU pair
     int fuse_diag;        // default 15; bit 0: in-block GEMMs, bit 1: trailing SYRK (multi-round), bit 2: sub-tiled diagonal tile, bit 3: single-round SYRK (sub-tiled)
     int diag_waves;       // (probe build only) 4: k_potrf_diag4 (default), 5: k_potrf_diag
@@ -92,6 +92,7 @@ struct gpmi_ctx {
     hipStream_t qstream[4];
     int nq;                  // number of mutually concurrent streams found (0 = not probed yet)
     int cal_want;            // ... the largest number a calibration run has searched for so far
+    int lanes_active;        // inside a multi-lane call (grid, table build, batch): other lanes' kernels share the chip
     int calibrate;           // 1: run grid lanes on qstream[]; 0: on the lanes' plain streams
 };
 

@@ -320,3 +320,21 @@ def test_sample_derivs_posterior_factored_at_an_odd_offset(ctx, orc, n, m):
     e_mu = np.max(np.abs(mu - mu_ref)) / np.max(np.abs(mu_ref)); e_d = np.max(np.abs(draw - draw_ref)) / np.max(np.abs(draw_ref))
     print("sample_derivs n=%d m=%d (odd offset): mu rel %.2e, draw rel %.2e" % (n, m, e_mu, e_d))
     assert e_mu <= RTOL and e_d <= 1e-7
+
+
+@pytest.mark.parametrize("n", [4700, 6001, 8192, 12289])
+def test_xcd_band_walk_of_the_trailing_updates_equals_row_major(ctx, n):
+    """syrk_order = 2 (XCD-partitioned band walk of the multi-round trailing updates, tail split per XCD, thin last
+    row as quadrants in its own workgroup) computes the same tiles with the same sums as the row-major walk: the
+    log marginal likelihood agrees to 1e-13 (which tiles take the quadrant path differs, nothing else)."""
+    from gp_amd.synth import synth
+    X, y = synth(n, 3)
+    try:
+        ctx.set_option("syrk_order", 0)
+        a = ctx.logml(X, y, 1.0, [0.3], 0.1)
+        ctx.set_option("syrk_order", 2)
+        b = ctx.logml(X, y, 1.0, [0.3], 0.1)
+    finally:
+        ctx.set_option("syrk_order", 2)
+    print("n=%d: row-major %.12e, XCD bands %.12e, rel %.1e" % (n, a[0], b[0], abs(a[0] - b[0]) / abs(a[0])))
+    assert abs(a[0] - b[0]) <= 1e-13 * abs(a[0]) and abs(a[2] - b[2]) <= 1e-12 * abs(a[2])

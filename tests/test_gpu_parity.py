@@ -31,7 +31,7 @@ for n in (900, 2048):  # 2048: a multiple of the tile size, where the augmented 
     X, y = synth(n, 3)
     base = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
     for opt, v, back in (("gemm_variant", 0, 3), ("gemm_variant", 1, 3), ("gemm_variant", 2, 3), ("lookahead", 1, 0),
-                         ("syrk_order", 1, 0), ("diag_waves", 5, 4)):
+                         ("syrk_order", 1, 2), ("syrk_order", 0, 2), ("diag_waves", 5, 4)):
         ctx.set_option(opt, v)
         got = ctx.logml(X, y, 1.0, [0.3], 0.1)[0]
         ctx.set_option(opt, back)
