@@ -21,7 +21,7 @@ SYMBOLS = (
     "gpmi_set_stream", "gpmi_reset_stream", "gpmi_sync", "gpmi_reserve", "gpmi_set_option",
     "gpmi_se_cov", "gpmi_se_cov_dev", "gpmi_deriv_cov", "gpmi_deriv_cov_dev", "gpmi_deriv_elem",
     "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
-    "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev",
+    "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev", "gpmi_logml_grid_ard", "gpmi_logml_grid_ard_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_joint_logml_grid_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition", "gpmi_sample_derivs", "gpmi_sample_derivs_batch",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
     "gpmi_interp_free", "gpmi_logml_grad", "gpmi_logml_grad_grid",
@@ -271,6 +271,19 @@ class Context:
                                        _p(info)))
         return out, info
 
+    def logml_grid_ard(self, X, y, alpha, ell, sigma, jitter=0.0):
+        """ARD grid: ell is (G, D), one length-scale per dimension and point; returns (G, 3), info (G,)."""
+        X = _mat(X); y = _vec(y)
+        n, D = X.shape
+        E = np.ascontiguousarray(np.asarray(ell, dtype=np.float64).reshape(-1, D))
+        G = E.shape[0]
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, float), (G,)))
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, float), (G,)))
+        out = np.empty((G, 3)); info = np.zeros(G, dtype=np.int32)
+        _chk(self._lib.gpmi_logml_grid_ard(self._h, _p(X), n, n, D, _p(y), _p(a), _p(E), _p(s), G, _d(jitter), _p(out),
+                                           _p(info)))
+        return out, info
+
     def joint_logml(self, t, yy, alpha, l, sigma, jitter=1e-6):
         t = _vec(t); yy = _vec(yy)
         if yy.size != 2 * t.size:
@@ -412,6 +425,14 @@ class Context:
         _chk(self._lib.gpmi_logml_grid_dev(self._h, C.c_void_p(dX_ptr), int(n), int(ldx), int(D),
                                            C.c_void_p(dy_ptr), _p(a), _p(r), _p(s), int(a.size), _d(jitter),
                                            C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
+
+    def logml_grid_ard_dev(self, dX_ptr, n, ldx, D, dy_ptr, alpha, ell, sigma, jitter, dout_ptr, dinfo_ptr):
+        E = np.ascontiguousarray(np.asarray(ell, dtype=np.float64).reshape(-1, int(D)))
+        G = E.shape[0]
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, float), (G,)))
+        s = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, float), (G,)))
+        _chk(self._lib.gpmi_logml_grid_ard_dev(self._h, C.c_void_p(dX_ptr), int(n), int(ldx), int(D), C.c_void_p(dy_ptr),
+                                               _p(a), _p(E), _p(s), G, _d(jitter), C.c_void_p(dout_ptr), C.c_void_p(dinfo_ptr)))
 
     def joint_logml_dev(self, dt_ptr, n, dyy_ptr, alpha, l, sigma, jitter, dout_ptr, dinfo_ptr):
         _chk(self._lib.gpmi_joint_logml_dev(self._h, C.c_void_p(dt_ptr), int(n), C.c_void_p(dyy_ptr), _d(alpha),

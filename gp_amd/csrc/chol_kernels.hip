@@ -1795,6 +1795,28 @@ __global__ __launch_bounds__(256, 2) void k_logml_small_batch(const double *__re
                      info_out + g, info_w + g, ec);
 }
 
+// the same with one length-scale PER DIMENSION and point (ARD grids: QQard takes a vector phi[[2]], R/kernels.R:11-19);
+// 32 points per launch (their D <= 8 inverse length-scales travel as kernel arguments too)
+constexpr int SMALL_PTS_ARD = 32;
+struct SmallBatchArd {
+    double a2[SMALL_PTS_ARD], diag[SMALL_PTS_ARD], inv_ell[SMALL_PTS_ARD][GPMI_MAXD];
+};
+__global__ __launch_bounds__(256, 2) void k_logml_small_batch_ard(const double *__restrict__ X, int n, int ldx, int D,
+                                                               const double *__restrict__ y, SmallBatchArd b,
+                                                               double *__restrict__ Wall, size_t wstride, size_t ld,
+                                                               double *__restrict__ out3, int *info_out, int *info_w, ExpC ec)
+{
+    GPMI_SMALL_LDS
+    const int g = blockIdx.x;
+    SmallSe se;
+    se.a2 = b.a2[g];
+    se.D = D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = b.inv_ell[g][d];
+    logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, b.diag[g], Wall + (size_t)g * wstride, ld, out3 + 3 * (size_t)g,
+                     info_out + g, info_w + g, ec);
+}
+
 // the factorisation alone (launch_potrf_partial at small sizes: posteriors, rbf_cov_chol, ...)
 __global__ __launch_bounds__(256, 2) void k_potrf_small(double *__restrict__ W, size_t ld, int M, int ncol, int nfac, int *info)
 {
@@ -2104,6 +2126,7 @@ static void small_lds_attr()
     const int bytes = SMALL_LDS_DOUBLES * (int)sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_ard), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done[dev] = true;
 }
@@ -2681,6 +2704,25 @@ void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, i
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_small_batch, dim3(G), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall, stride, ld, d_out3, d_info_out,
                        d_info_work, h_exp);
+}
+
+// G <= GPMI_SMALL_PTS_ARD points with a length-scale per dimension: ell is G x D, point-major
+void launch_logml_small_batch_ard(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                                  const double *ell, const double *sigma, int G, double jitter, double *Wall, double *d_out3,
+                                  int *d_info_out, int *d_info_work)
+{
+    static_assert(SMALL_PTS_ARD == GPMI_SMALL_PTS_ARD, "batch size of the small-N ARD grid launch");
+    SmallBatchArd b;
+    for (int g = 0; g < G; ++g) {
+        b.a2[g] = alpha[g] * alpha[g];
+        b.diag[g] = sigma[g] * sigma[g] + jitter;
+        for (int d = 0; d < GPMI_MAXD; ++d) b.inv_ell[g][d] = d < D ? 1.0 / ell[(size_t)g * D + d] : 0.0;
+    }
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_logml_small_batch_ard, dim3(G), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall,
+                       stride, ld, d_out3, d_info_out, d_info_work, h_exp);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

@@ -980,6 +980,49 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
     return 0;
 }
 
+// ARD grid: one length-scale per dimension and point (ell: G x D, point-major).  QQard's phi[[2]] is a vector
+// (R/kernels.R:11-19): a grid search / optimiser over ARD length-scales evaluates exactly this.
+extern "C" int gpmi_logml_grid_ard_dev(gpmi_ctx *c, const double *dX, int n, int ldx, int D, const double *dy,
+                                       const double *alpha, const double *ell, const double *sigma, int G, double jitter,
+                                       double *d_out3, int *d_info)
+{
+    ENTER(c);
+    if (G < 0) return gpmi_fail(GPMI_EARG, "negative grid size");
+    if (G == 0) return 0;
+    if (n <= 0 || !dX || !dy || !alpha || !ell || !sigma || !d_out3 || !d_info || ldx < n)
+        return gpmi_fail(GPMI_EARG, "bad argument");
+    int rc;
+    std::vector<SeParams> ps(G);
+    for (int g = 0; g < G; ++g)
+        if ((rc = fill_params(&ps[g], D, alpha[g], ell + (size_t)g * D, D))) return rc;
+    if (small_logml(c, n, D, G)) {
+        const int per = G < GPMI_SMALL_PTS_ARD ? G : GPMI_SMALL_PTS_ARD;
+        if ((rc = reserve_ws_small(c, n, per))) return rc;
+        for (int g0 = 0; g0 < G; g0 += GPMI_SMALL_PTS_ARD) {
+            const int gc = (G - g0 < GPMI_SMALL_PTS_ARD) ? G - g0 : GPMI_SMALL_PTS_ARD;
+            launch_logml_small_batch_ard(c->stream, dX, n, ldx, D, dy, alpha + g0, ell + (size_t)g0 * D, sigma + g0, gc, jitter,
+                                         c->W, d_out3 + 3 * (size_t)g0, d_info + g0, c->d_ctr + 64);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : 4));
+    if (lanes > 8) lanes = 8;
+    if (lanes > G) lanes = G;
+    if ((rc = lanes_prepare(c, lanes))) return rc;
+    const int la_saved = c->lookahead;
+    hipStream_t const caller = c->stream;
+    lanes_fork(c, lanes, caller);
+    for (int g = 0; g < G && !rc; ++g) {
+        gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
+        rc = logml_core(lc, dX, n, ldx, dy, ps[g], sigma[g] * sigma[g] + jitter, d_out3 + 3 * (size_t)g, d_info + g);
+    }
+    lanes_join(c, lanes, caller, la_saved);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int upload_xy(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y, double **dX, double **dy)
 {
     int rc;
@@ -1058,6 +1101,25 @@ extern "C" int gpmi_logml_grid(gpmi_ctx *c, const double *X, int n, int ldx, int
     if ((rc = scratch_buf(c, (size_t)G * (3 * sizeof(double) + sizeof(int)) + 64, &dres))) return rc;
     int *dinfo = (int *)(dres + 3 * (size_t)G);
     if ((rc = gpmi_logml_grid_dev(c, dX, n, n, D, dy, alpha, rho, sigma, G, jitter, dres, dinfo))) return rc;
+    HIPCHK(hipMemcpyAsync(out3, dres, (size_t)G * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int gpmi_logml_grid_ard(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y, const double *alpha,
+                                   const double *ell, const double *sigma, int G, double jitter, double *out3, int *info)
+{
+    ENTER(c);
+    if (G < 0) return gpmi_fail(GPMI_EARG, "negative grid size");
+    if (G == 0) return 0;
+    if (n <= 0 || !X || !y || !out3 || !info || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
+    double *dX, *dy, *dres;
+    int rc;
+    if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
+    if ((rc = scratch_buf(c, (size_t)G * (3 * sizeof(double) + sizeof(int)) + 64, &dres))) return rc;
+    int *dinfo = (int *)(dres + 3 * (size_t)G);
+    if ((rc = gpmi_logml_grid_ard_dev(c, dX, n, n, D, dy, alpha, ell, sigma, G, jitter, dres, dinfo))) return rc;
     HIPCHK(hipMemcpyAsync(out3, dres, (size_t)G * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

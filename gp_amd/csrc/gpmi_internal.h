@@ -10,6 +10,7 @@
 #define GPMI_MAXD 8          // dimensions the register-resident fast path handles
 #define GPMI_MAXD_BIG 64     // dimensions the generic path handles (inverse length-scales in kernel arguments)
 #define GPMI_SMALL_PTS 128   // grid points per launch of the one-workgroup-per-point small-N kernel
+#define GPMI_SMALL_PTS_ARD 32 // ... with a length-scale per dimension and point
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -157,6 +158,9 @@ void small_ws_layout(int n, size_t *ld, size_t *stride);
 void launch_logml_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
                         double *W, size_t ld, double *d_out3, int *d_info_out, int *d_info_work,
                         double *stage /* nullable: device staging for host-mapped X, y */);
+void launch_logml_small_batch_ard(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                                  const double *ell /* G x D, point-major */, const double *sigma, int G, double jitter,
+                                  double *Wall, double *d_out3, int *d_info_out, int *d_info_work);
 void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                               const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_out3,
                               int *d_info_out, int *d_info_work);

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GPMI_VERSION 201
+#define GPMI_VERSION 301
 
 /* the ABI: the ONLY symbols libgpmi.so exports (it is built with -fvisibility=hidden) */
 #define GPMI_API __attribute__((visibility("default")))
@@ -179,6 +179,16 @@ GPMI_API int gpmi_logml_grid(gpmi_ctx *ctx, const double *X, int n, int ldx, int
 GPMI_API int gpmi_logml_grid_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
                         const double *alpha, const double *rho, const double *sigma, int G,
                         double jitter, double *d_out3, int *d_info);
+
+/* The same grid with ONE LENGTH-SCALE PER DIMENSION and point (ARD): ell is G x D, point-major (ell[g * D + d]).
+ * QQard(X, Y, phi) takes a vector phi[[2]] (R/kernels.R:11-19); a grid search or optimiser over ARD
+ * length-scales evaluates exactly this.  Everything else as gpmi_logml_grid. */
+GPMI_API int gpmi_logml_grid_ard(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, const double *y,
+                        const double *alpha, const double *ell, const double *sigma, int G,
+                        double jitter, double *out3, int *info);
+GPMI_API int gpmi_logml_grid_ard_dev(gpmi_ctx *ctx, const double *dX, int n, int ldx, int D, const double *dy,
+                            const double *alpha, const double *ell, const double *sigma, int G,
+                            double jitter, double *d_out3, int *d_info);
 
 /* Log marginal likelihood of stacked observations yy = [y; y'] (length 2n)
  * under gpmi_joint_cov's matrix (BASELINE config c5). */

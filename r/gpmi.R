@@ -100,6 +100,15 @@ gp_log_marginal_grid <- function(X, y, alpha, rho_vec, sigma_vec, jitter = 0) {
   matrix(r[[1]][1, ], nrow = length(rho_vec), ncol = length(sigma_vec))
 }
 
+# ARD points: ell_mat is D x G (column g = the length-scale vector of point g, QQard's phi[[2]]); returns logml per point
+gp_log_marginal_points_ard <- function(X, y, alpha, ell_mat, sigma, jitter = 0) {
+  ell_mat <- as.matrix(ell_mat); storage.mode(ell_mat) <- "double"
+  G <- ncol(ell_mat)
+  r <- .Call("gpmi_R_logml_grid_ard", as.matrix(X), as.double(y), rep_len(as.double(alpha), G), ell_mat,
+             rep_len(as.double(sigma), G), jitter)
+  r[[1]][1, ]
+}
+
 # arg-max over the grid: mirror of get_ml_from_stan_samples, R/tests.R:21-27
 get_ml_from_grid <- function(values, alpha, rho_vec, sigma_vec) {
   idx <- which(values == max(values, na.rm = TRUE), arr.ind = TRUE)[1, ]

@@ -262,6 +262,25 @@ SEXP gpmi_R_logml_grid(SEXP X, SEXP y, SEXP alpha, SEXP rho, SEXP sigma, SEXP ji
     return out;
 }
 
+/* the same grid with a length-scale per dimension and point: ell is a D x G matrix (column g = point g), QQard's vector
+ * phi[[2]] (R/kernels.R:11-19) */
+SEXP gpmi_R_logml_grid_ard(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X), G = Rf_ncols(ell);
+    need(is_real(X) && is_real(y) && is_real(alpha) && is_real(ell) && is_real(sigma), "X, y, alpha, ell, sigma must be double");
+    need(Rf_length(y) == n, "length(y) must equal nrow(X)");
+    need(Rf_nrows(ell) == D, "ell must be ncol(X) x (grid points)");
+    need(Rf_length(alpha) == G && Rf_length(sigma) == G, "alpha and sigma must have one entry per grid point (recycle in R)");
+    SEXP res = PROTECT(Rf_allocMatrix(REALSXP, 3, G)), info = PROTECT(Rf_allocVector(INTSXP, G));
+    int rc = gpmi_logml_grid_ard(ctx(), REAL(X), n, n, D, REAL(y), REAL(alpha), REAL(ell), REAL(sigma), G, Rf_asReal(jitter),
+                                 REAL(res), INTEGER(info));
+    SEXP out = PROTECT(Rf_allocVector(VECSXP, 2));
+    SET_VECTOR_ELT(out, 0, res); SET_VECTOR_ELT(out, 1, info);
+    UNPROTECT(3);
+    check(rc);
+    return out;
+}
+
 /* list(mn, Kn): p_Xn / p_dotXn (R/ode_gp.R:1-32, R/ode_gp_library.R:4-33), sample_derivs moments
  * (pendulum_fit.R:242-251) */
 SEXP gpmi_R_gp_condition(SEXP t, SEXP ts, SEXP y, SEXP alpha, SEXP l, SEXP s2, SEXP jitter, SEXP kinds, SEXP flags)

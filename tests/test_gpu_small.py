@@ -155,3 +155,23 @@ def test_default_thresholds_agree_across_the_switch_points(ctx, orc):
         want = orc.logml(X, y, 1.0, 0.8, 0.1)
         assert np.all(info == 0) and abs(single[0] - want[0]) <= RTOL * abs(want[0])
         assert np.max(np.abs(out[:, 0] - single[0])) <= 1e-12 * abs(single[0]), (n, out[:, 0], single)
+
+
+@pytest.mark.parametrize("n,D", [(60, 3), (256, 8), (700, 4), (300, 12)])
+def test_ard_grid_equals_single_ard_evaluations(ctx, orc, n, D):
+    """gpmi_logml_grid_ard: one length-scale per dimension and point (QQard's vector phi[[2]], R/kernels.R:11-19) --
+    through the one-workgroup batch kernel (n <= 256, D <= 8: 32 points per launch), the lanes (n = 700) and the
+    LDS-tiled builder (D = 12): every point equals the single ARD evaluation bit for bit and the oracle to 1e-8."""
+    X, y = _case(n, D, 21)
+    G = 40
+    rng = np.random.default_rng(n + D)
+    ell = 0.5 + rng.random((G, D)) * 1.5; alpha = 0.8 + 0.4 * rng.random(G); sig = 0.1 + 0.2 * rng.random(G)
+    ell[7] = 80.0; sig[7] = 1e-9      # not positive definite in fp64
+    out, info = ctx.logml_grid_ard(X, y, alpha, ell, sig)
+    assert info[7] > 0 and np.all(np.isnan(out[7])) and np.all(np.delete(info, 7) == 0)
+    for g in (0, 6, 8, 31, 32, 39):
+        single = ctx.logml(X, y, alpha[g], ell[g], sig[g])
+        assert tuple(out[g]) == tuple(single), (g, out[g], single)
+    for g in (1, 33):
+        want = orc.logml(X / ell[g], y, alpha[g], 1.0, sig[g])
+        assert abs(out[g, 0] - want[0]) <= RTOL * abs(want[0])
