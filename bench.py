@@ -261,6 +261,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    coll_group, coll_backend = None, None   # group / backend of the data-path collectives (None: default group)
     if args.rehearse:
         local_rank = 0
     if local_rank >= torch.cuda.device_count():
@@ -272,10 +273,32 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if args.rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # Rendezvous and agreement channel: gloo.  Data-path collectives: RCCL ("nccl") over xGMI, as its own group.  If
+        # RCCL cannot come up on this node (every rank reports through the gloo channel; a stuck communicator creation is
+        # aborted by its timeout) the run is not thrown away: the one gather is 32 B per point, so it goes over gloo on
+        # host tensors and the line says so (`collective_backend`); evaluations and timing are unaffected.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if not args.rehearse:
+            import datetime
+            ok_here, note = 1, ""
+            try:
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=g)  # creates the communicator now, not inside the timed region
+                torch.cuda.synchronize(dev)
+                ok_here = int(float(probe.item()) == float(world))
+            except Exception as e:               # noqa: BLE001 -- any RCCL failure
+                ok_here, note = 0, repr(e)[:160]
+            flag = torch.tensor([ok_here], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                coll_group, coll_backend = g, "nccl"
+            else:
+                sys.stderr.write("bench.py rank %d: nccl unavailable on some rank (%s); the gather goes over gloo\n" % (rank, note))
+                args.rehearse_collectives = True
+                coll_backend = "gloo (nccl unavailable%s)" % ((": " + note) if note else " on another rank")
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            coll_backend = "gloo (--rehearse)"
         world = dist.get_world_size()   # what the collective layer actually sees
 
     import gp_amd
@@ -304,7 +327,7 @@ def main():
     # on ONE explicit torch stream, so the collective is ordered behind the evaluations it sends
     stream = torch.cuda.Stream(dev)
     ctx.set_stream(stream.cuda_stream)
-    cdev = torch.device("cpu") if args.rehearse else dev  # gloo rehearsal: collectives on host tensors
+    cdev = torch.device("cpu") if (args.rehearse or getattr(args, "rehearse_collectives", False)) else dev  # gloo: collectives on host tensors
 
     if args.workload == "c3":
         # rank r, step k evaluates its own hyper-parameter point near (rho, sigma) = (0.3, 0.1)
@@ -356,7 +379,7 @@ def main():
         device, ONE all_gather), on the current stream."""
         R, S = c4_grid()
         return logml_grid_sharded_dev(ctx, dX.data_ptr(), n, n, D, dy.data_ptr(), np.ones(C4_G), R, S, 0.0,
-                                      device=dev, comm_device=cdev)
+                                      group=coll_group, device=dev, comm_device=cdev)
 
     with torch.cuda.stream(stream):
         if args.workload == "c4":
@@ -367,7 +390,7 @@ def main():
             if distributed:  # the gather's buffers / channels exist before the timed region, like the workspaces
                 send = dout.to(cdev)
                 gathered = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(gathered, send)
+                dist.all_gather(gathered, send, group=coll_group)
         barrier()
         t0 = time.perf_counter()
         if args.workload == "c4":
@@ -380,7 +403,7 @@ def main():
                 # stream as the evaluations, so it reads them only after the lanes have joined
                 send = dout.to(cdev)
                 gathered = [torch.empty_like(send) for _ in range(world)]
-                dist.all_gather(gathered, send)
+                dist.all_gather(gathered, send, group=coll_group)
         barrier()
         elapsed = time.perf_counter() - t0
 
@@ -419,7 +442,7 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if distributed:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=coll_group)
     elapsed = float(tmax.item())
     if args.workload == "c4":
         f4 = full4.cpu().numpy()
@@ -439,7 +462,7 @@ def main():
 
         def sharded():   # the PRODUCT's multi-GPU function: gp_amd.grid.logml_grid_sharded_dev
             return logml_grid_sharded_dev(ctx, dX4.data_ptr(), C4_N, C4_N, C4_D, dy4.data_ptr(), np.ones(C4_G), R4, S4, 0.0,
-                                          device=dev, comm_device=cdev)
+                                          group=coll_group, device=dev, comm_device=cdev)
 
         def one_rank():  # all 64 points on this rank's GPU alone, same building block, no collective
             return logml_grid_local_dev(ctx, dX4.data_ptr(), C4_N, C4_N, C4_D, dy4.data_ptr(), np.ones(C4_G), R4, S4, 0.0, dev)
@@ -465,7 +488,7 @@ def main():
                 barrier()
         tt = torch.tensor([tN], dtype=torch.float64, device=cdev)
         if distributed:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=coll_group)
         tN = float(tt.item())
         if rank == 0:
             got = got4.cpu().numpy()[:, :3]
@@ -524,6 +547,7 @@ def main():
                        "nb_outer": args.nb_outer or "auto(adaptive: %d for the first block, narrower as the trailing matrix shrinks)" % nbo_auto,
                        "parallelism": "independent hyper-parameter points per GPU; one RCCL all_gather of results"},
             "results_ok": ok,
+            "collective_backend": coll_backend,
             "launched_by": "bench.py launcher" if os.environ.get("GPMI_BENCH_LAUNCHED") else
                            ("torchrun / external" if distributed else "single process"),
             "grid_lanes": args.grid_lanes or "auto(4)",

@@ -15,21 +15,24 @@ if [ $PART = bench ] || [ $PART = all ]; then
 fi
 if [ $PART = prof ] || [ $PART = all ]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline --no-c4 > $O/prof_default.log 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline --no-c4 --no-c1 > $O/prof_default.log 2>&1
   grep '^{"metric"' $O/prof_default.log > $O/prof_default.json
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seq -- python3 $R/bench.py --grid-lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --no-c4 > $O/prof_seq.log 2>&1
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seq -- python3 $R/bench.py --grid-lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --no-c4 --no-c1 > $O/prof_seq.log 2>&1
   grep '^{"metric"' $O/prof_seq.log > $O/prof_seq.json
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seq_c4 -- python3 $R/bench.py --workload c4 --grid-lanes 1 --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_seq_c4.log 2>&1
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seq_c5 -- python3 $R/bench.py --workload c5 --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_seq_c5.log 2>&1
-  python3 $R/tools/prof_summary.py $O/prof_default $O/bench_c3_kernel_stats.txt "bench.py --no-cpu-baseline --no-c4 (default: 4 lanes; overlapping launches inflate durations)" > /dev/null
-  python3 $R/tools/prof_summary.py $O/prof_seq $O/bench_c3_sequential_kernel_stats.txt "bench.py --grid-lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --no-c4" > /dev/null
+  python3 $R/tools/prof_summary.py $O/prof_default $O/bench_c3_kernel_stats.txt "bench.py --no-cpu-baseline --no-c4 --no-c1 (default: 4 lanes; overlapping launches inflate durations)" > /dev/null
+  python3 $R/tools/prof_summary.py $O/prof_seq $O/bench_c3_sequential_kernel_stats.txt "bench.py --grid-lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --no-c4 --no-c1" > /dev/null
   python3 $R/tools/prof_summary.py $O/prof_seq_c4 $O/bench_c4_sequential_kernel_stats.txt "bench.py --workload c4 --grid-lanes 1 --steps 1 --warmup 1 (N = 8192, one evaluation at a time)" > /dev/null
   python3 $R/tools/prof_summary.py $O/prof_seq_c5 $O/bench_c5_kernel_stats.txt "bench.py --workload c5 --steps 4 --warmup 1 (joint [y, y'] covariance, order 16384)" > /dev/null
   rm -rf $O/prof_default $O/prof_seq $O/prof_seq_c4 $O/prof_seq_c5
   cd $R
 fi
 if [ $PART = pmc ] || [ $PART = all ]; then
-  bash $R/tools/pmc_bench.sh c3 16384
+  bash $R/tools/pmc_bench.sh c3 16384 --grid-lanes 1   # the configuration of bench.py's roofline pass: one evaluation at a time
+  cp $R/gpurun_out/pmc_bench_c3_n16384.json $R/gpurun_out/pmc_bench_c3_n16384_sequential.json
+  bash $R/tools/pmc_bench.sh c3 16384                  # default: 4 lanes + the sequential passes
+  mv $R/gpurun_out/pmc_bench_c3_n16384.json $R/gpurun_out/pmc_bench_c3_n16384_lanes4_mix.json
   bash $R/tools/pmc_bench.sh c4 8192 --steps 1   # (two back-to-back grid calls under --pmc hang in the profiler; one step is 64 evaluations anyway)
   bash $R/tools/pmc_bench.sh c5 16384
 fi
