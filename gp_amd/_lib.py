@@ -29,7 +29,7 @@ SYMBOLS = (
     "gpmi_last_timing", "gpmi_kernel_timing", "gpmi_kernel_timing_ex",
 )
 # additionally exported by the probe build (libgpmi_probes.so, -DGPMI_PROBES; tools/ only)
-PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock", "gpmi_probe_fused", "gpmi_probe_small")
+PROBE_SYMBOLS = ("gpmi_probe_syrk", "gpmi_probe_mfma", "gpmi_probe_mfma_peak", "gpmi_probe_clock", "gpmi_probe_fused", "gpmi_probe_small", "gpmi_probe_body")
 
 
 class GpmiError(RuntimeError):
@@ -480,8 +480,14 @@ class Context:
         return out[0] / max(out[1], 1.0) * 100.0, out[0] / out[2], int(out[2])
 
     def probe_fused(self):
-        out = np.zeros(5)
+        out = np.zeros(8)
         _chk(self._probe("gpmi_probe_fused")(self._h, _p(out)))
+        return out
+
+    def probe_body(self):
+        """(loads, loop, stores, factor16, factor-wave wait, bodies): cycles of the diagonal-block bodies since the last call."""
+        out = np.zeros(6)
+        _chk(self._probe("gpmi_probe_body")(self._h, _p(out)))
         return out
 
     def probe_small(self):

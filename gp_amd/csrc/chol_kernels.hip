@@ -185,6 +185,17 @@ __global__ __launch_bounds__(320) void k_potrf_diag(double *__restrict__ A, size
 // microseconds instead of waiting for a whole CU to drain by chance (5 waves need two wave
 // slots with ~200 registers each on one SIMD, which a resident SYRK wave rules out).
 // ---------------------------------------------------------------------------
+#ifdef GPMI_PROBES
+// where a diagonal-block body spends its cycles (accumulated over all bodies since the last read): [0] block loads
+// (drained), [1] the 8-step loop, [2] stores, [3] factor wave inside factor16, [4] factor wave waiting at B1 for the
+// next diagonal tile, [5] bodies
+__device__ unsigned long long g_body[8];
+#define GPMI_BSTAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime();
+#define GPMI_BADD(i, d) atomicAdd(&g_body[i], (unsigned long long)(d));
+#else
+#define GPMI_BSTAMP(v)
+#define GPMI_BADD(i, d)
+#endif
 template <bool COH>
 __device__ __forceinline__ double ld_blk(const double *p)
 {
@@ -221,36 +232,66 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     // diagonal tile needs nothing but its owner's own solve result (register r of X is, lane for lane,
     // the A and the B operand of X X^T), so no barrier stands between the solve and that update (the
     // third barrier of the earlier form cost ~2 k of the ~7.7 k cycles per step).
+    // The barriers order LDS traffic only (the waves talk through s_d16 / s_inv / s_pub): they are raw
+    // s_waitcnt lgkmcnt(0) + s_barrier, NOT __syncthreads(), whose release fence also drains vmcnt -- so the block's
+    // global loads may still be in flight at the first barriers (they are issued in the order they are needed: block
+    // column 0 of every row first) and the finished tiles are stored from inside the loop, under the factor wave's
+    // time, instead of in a ~6 k-cycle tail behind it.  Nothing in the body reads global memory another wave of the
+    // workgroup has written.
+#define GPMI_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     if (w == 3) {
 #pragma unroll 1
         for (int kb = 0; kb < nblk; ++kb) {
-            __syncthreads();  // B1: the owner's diagonal tile is in s_d16[kb & 1]; -X tiles of step kb - 1 published
+            GPMI_BSTAMP(f0)
+            GPMI_LDS_BARRIER();  // B1: the owner's diagonal tile is in s_d16[kb & 1]; -X tiles of step kb - 1 published
+            GPMI_BSTAMP(f1)
             const int bad = factor16(s_d16[kb & 1], s_inv[kb], lane);
             if (bad && lane == 0) atomicCAS(info, 0, col0 + kb * 16 + bad);
-            __syncthreads();  // B2: L16 in s_d16[kb & 1], L16^-1 in s_inv[kb]
+            GPMI_BSTAMP(f2)
+#ifdef GPMI_PROBES
+            if (lane == 0) {
+                GPMI_BADD(3, f2 - f1)
+                GPMI_BADD(4, f1 - f0)
+            }
+#endif
+            GPMI_LDS_BARRIER();  // B2: L16 in s_d16[kb & 1], L16^-1 in s_inv[kb]
         }
         return;
     }
+    GPMI_BSTAMP(b0)
 
     // block-rows of this wave, ra > rb > rc (rc = -1: none); array sizes cover the largest row of each class
     const int ra = 7 - w, rb = 2 + w, rc = w < 2 ? w : -1;
     d4 TA[8], TB[5], TC[2];
 #define GPMI_CL(jb, NJ) ((jb) < (NJ) ? (jb) : 0)  // keeps compile-time indices of never-taken branches in range
-#define GPMI_LOAD_ROW(T, NJ, br)                                                                       \
-    _Pragma("unroll") for (int jb = 0; jb < (NJ); ++jb) {                                              \
+    // per block-row: A + (16 br + lr) + lq lda -- element (i) of tile jb is then a wave-uniform multiple of lda away
+    // (the general form costs a max / min / 64-bit multiply-add per element: 4.5 k cycles of pure address arithmetic
+    // for the 60 loads of a lane)
+    const double *const pra = A + (size_t)(ra * 16 + lr) + (size_t)lq * lda;
+    const double *const prb = A + (size_t)(rb * 16 + lr) + (size_t)lq * lda;
+    const double *const prc = A + (size_t)((rc < 0 ? 0 : rc) * 16 + lr) + (size_t)lq * lda;
+#define GPMI_LOAD_TILE(T, br, jb, PR)                                                                  \
+    {                                                                                                  \
         T[jb] = d4{0.0, 0.0, 0.0, 0.0};                                                                \
-        if (jb <= (br)) {                                                                              \
+        if (FULL && (jb) < (br)) {                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) T[jb][i] = ld_blk<COH>(PR + (size_t)((jb) * 16 + 4 * i) * lda); \
+        } else if ((jb) <= (br)) {                                                                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-                const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
+                const int col = (jb) * 16 + lq + 4 * i, row = (br) * 16 + lr;                          \
                 const int rr = row > col ? row : col, cc = row > col ? col : row;                      \
                 if (FULL) T[jb][i] = ld_blk<COH>(A + (size_t)rr + (size_t)cc * lda);                   \
                 else T[jb][i] = (rr < nb_act) ? ld_blk<COH>(A + (size_t)rr + (size_t)cc * lda) : (row == col ? 1.0 : 0.0); \
             }                                                                                          \
         }                                                                                              \
     }
-    GPMI_LOAD_ROW(TA, 8, ra)
-    GPMI_LOAD_ROW(TB, 5, rb)
-    GPMI_LOAD_ROW(TC, 2, rc)
+    // block column by block column, lowest rows first: tile (0, 0) and then the tiles of block column 0 are what the
+    // first steps wait for
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        if (jb < 2) GPMI_LOAD_TILE(TC, rc, jb, prc)
+        if (jb < 5) GPMI_LOAD_TILE(TB, rb, jb, prb)
+        GPMI_LOAD_TILE(TA, ra, jb, pra)
+    }
 
 #define GPMI_SOLVE_ROW(T, NJ, br, X)                                                                   \
     if ((br) == kb) {                                                                                  \
@@ -260,13 +301,6 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
             X = mfma(s_inv[kb][kg * 64 + lane], T[GPMI_CL(kb, NJ)][kg], X);                            \
         T[GPMI_CL(kb, NJ)] = X;                                                                        \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) s_pub[kb & 1][br][kg * 64 + lane] = -X[kg];   \
-    }
-#define GPMI_UPDATE_ROW(T, NJ, br, X)                                                                  \
-    _Pragma("unroll") for (int jb = kb + 1; jb < (NJ); ++jb) {                                         \
-        if (jb <= (br)) {                                                                              \
-            _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                           \
-                T[jb] = mfma(s_pub[kb & 1][jb][kg * 64 + lane], X[kg], T[jb]);                         \
-        }                                                                                              \
     }
 
     // The only tile the next pivot block waits for is the diagonal tile of block-row kb + 1: its
@@ -286,22 +320,46 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
                 T[jb] = mfma(s_pub[(kb - 1) & 1][jb][kg * 64 + lane], X[kg], T[jb]);                   \
         }                                                                                              \
     }
+    // Block column k of block-row br is final once step k has solved it: L tile (from the solve's registers) and its
+    // packed negative below the diagonal; on the diagonal the factor's tile and the inverse the factor wave left in
+    // s_inv[k].  Issued one step later, behind B1, so that the stores do not sit between B2 and B1 (the critical path).
+#define GPMI_STORE_STEP(T, NJ, br, k, PR)                                                              \
+    if ((br) > (k)) {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            if (FULL || (br) * 16 + lr < nb_act)                                                       \
+                const_cast<double *>(PR)[(size_t)((k) * 16 + 4 * i) * lda] = T[GPMI_CL(k, NJ)][i];     \
+        }                                                                                              \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
+            Fpack[(size_t)fp_l(br, k) * 256 + kg * 64 + lane] = -T[GPMI_CL(k, NJ)][kg];                \
+    } else if ((br) == (k)) {                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+            const int col = (k) * 16 + lq + 4 * i, row = (br) * 16 + lr;                               \
+            if (col <= row && (FULL || row < nb_act)) A[(size_t)row + (size_t)col * lda] = T[GPMI_CL(k, NJ)][i]; \
+        }                                                                                              \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
+            Fpack[(size_t)fp_inv(k) * 256 + kg * 64 + lane] = s_inv[k][kg * 64 + lane];                \
+    }
 
+    GPMI_BSTAMP(b1)
     d4 XA[8], XB[8], XC[8];
     if (rc == 0) {  // block-row 0 hands tile (0, 0) to the factor wave in matrix order
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_d16[0][lr][lq + 4 * i] = TC[0][i];
     }
+    int last = -1;  // last step whose tiles are not stored yet
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         if (!FULL && kb >= nblk) break;  // workgroup-uniform
-        __syncthreads();  // B1: diagonal tile kb is in s_d16[kb & 1]; every wave's -X tiles of step kb - 1 are published
-        if (kb > 0) {     // REST of step kb - 1: tiles jb >= kb of the rows below, except tile (kb, kb)
+        GPMI_LDS_BARRIER();  // B1: diagonal tile kb is in s_d16[kb & 1]; every wave's -X tiles of step kb - 1 are published
+        if (kb > 0) {     // tiles of step kb - 1 out; REST of step kb - 1: tiles jb >= kb of the rows below, except tile (kb, kb)
+            GPMI_STORE_STEP(TA, 8, ra, kb - 1, pra)
+            GPMI_STORE_STEP(TB, 5, rb, kb - 1, prb)
+            GPMI_STORE_STEP(TC, 2, rc, kb - 1, prc)
             if (ra >= kb) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
             if (rb >= kb) { GPMI_UPDATE_REST(TB, 5, rb, XB[kb - 1]) }
             if (rc >= kb) { GPMI_UPDATE_REST(TC, 2, rc, XC[kb - 1]) }
         }
-        __syncthreads();  // B2: factor wave done
+        GPMI_LDS_BARRIER();  // B2: factor wave done
         XA[kb] = d4{0.0, 0.0, 0.0, 0.0};
         XB[kb] = XA[kb];
         XC[kb] = XA[kb];
@@ -313,38 +371,35 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
             else if (rb == kb + 1) GPMI_UPDATE_EARLY(TB, 5, rb, XB[kb])
             else if (rc == kb + 1) GPMI_UPDATE_EARLY(TC, 2, rc, XC[kb])
         }
+        last = kb;
     }
 #undef GPMI_UPDATE_EARLY
 #undef GPMI_UPDATE_REST
-
-#define GPMI_STORE_ROW(T, NJ, br)                                                                      \
-    _Pragma("unroll") for (int jb = 0; jb < (NJ); ++jb) {                                              \
-        if (jb <= (br)) {                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-                const int col = jb * 16 + lq + 4 * i, row = (br) * 16 + lr;                            \
-                if (FULL ? (jb < (br) || col <= row) : (row < nb_act && col <= row))                   \
-                    A[(size_t)row + (size_t)col * lda] = T[jb][i];                                     \
-            }                                                                                          \
-            if (jb < (br)) {                                                                           \
-                _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                       \
-                    Fpack[(size_t)((br) * ((br) - 1) / 2 + jb) * 256 + kg * 64 + lane] = -T[jb][kg];   \
-            }                                                                                          \
-        }                                                                                              \
-    }
-    GPMI_STORE_ROW(TA, 8, ra)
-    GPMI_STORE_ROW(TB, 5, rb)
-    GPMI_STORE_ROW(TC, 2, rc)
+    GPMI_BSTAMP(b2)
+    // the last step's tiles (compile-time step index: one copy per possible last step of a ragged block)
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-        Fpack[(size_t)fp_inv(ra) * 256 + kg * 64 + lane] = s_inv[ra][kg * 64 + lane];
-        Fpack[(size_t)fp_inv(rb) * 256 + kg * 64 + lane] = s_inv[rb][kg * 64 + lane];
-        if (rc >= 0) Fpack[(size_t)fp_inv(rc) * 256 + kg * 64 + lane] = s_inv[rc][kg * 64 + lane];
+    for (int k = 0; k < 8; ++k) {
+        if (k == last) {
+            GPMI_STORE_STEP(TA, 8, ra, k, pra)
+            GPMI_STORE_STEP(TB, 5, rb, k, prb)
+            GPMI_STORE_STEP(TC, 2, rc, k, prc)
+        }
     }
+#ifdef GPMI_PROBES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (w == 0 && lane == 0) {
+        GPMI_BSTAMP(b3)
+        GPMI_BADD(0, b1 - b0)
+        GPMI_BADD(1, b2 - b1)
+        GPMI_BADD(2, b3 - b2)
+        GPMI_BADD(5, 1)
+    }
+#endif
 #undef GPMI_CL
-#undef GPMI_LOAD_ROW
+#undef GPMI_LOAD_TILE
 #undef GPMI_SOLVE_ROW
-#undef GPMI_UPDATE_ROW
-#undef GPMI_STORE_ROW
+#undef GPMI_STORE_STEP
+#undef GPMI_LDS_BARRIER
 }
 
 __global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, size_t lda, int nb_act,
@@ -1011,6 +1066,11 @@ __device__ __forceinline__ void fused_subtiles_and_diag(double (&smem)[2][2][GK]
         atomicAdd(&g_fz[2], __builtin_amdgcn_s_memtime() - fz2);
         atomicAdd(&g_fz[3], 1ull);
         atomicAdd(&g_fz[4], (unsigned long long)K);
+        if (K == 128) {  // leaf launches: the body IS the critical path there
+            atomicAdd(&g_fz[5], __builtin_amdgcn_s_memtime() - fz2);
+            atomicAdd(&g_fz[6], fz1 - fz0);
+            atomicAdd(&g_fz[7], 1ull);
+        }
     }
 #endif
 }
@@ -2767,6 +2827,14 @@ int probe_fused_read(hipStream_t s, unsigned long long *out5)
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
     if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_fz), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fz), z, sizeof z) != hipSuccess;
+}
+
+int probe_body_read(hipStream_t s, unsigned long long *out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_body), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_body), z, sizeof z) != hipSuccess;
 }
 
 int probe_clock_read(hipStream_t s, int reset, unsigned long long *out3)

@@ -2492,7 +2492,19 @@ extern "C" int gpmi_probe_fused(gpmi_ctx *c, double *out5)
     ENTER(c);
     unsigned long long h[8];
     if (probe_fused_read(c->stream, h)) return gpmi_fail(GPMI_EHIP, "probe read failed");
-    for (int i = 0; i < 5; ++i) out5[i] = (double)h[i];
+    for (int i = 0; i < 8; ++i) out5[i] = (double)h[i];   // [5..7]: body cycles, sub-tile cycles, launches of the K = 128 leaf launches
+    return 0;
+}
+
+int probe_body_read(hipStream_t s, unsigned long long *out8);
+// out6: diagonal-block bodies since the last call: cycles in the block loads, the 8-step loop, the stores (tile wave 0),
+// inside factor16 and waiting for the next diagonal tile (factor wave); number of bodies
+extern "C" int gpmi_probe_body(gpmi_ctx *c, double *out6)
+{
+    ENTER(c);
+    unsigned long long h[8];
+    if (probe_body_read(c->stream, h)) return gpmi_fail(GPMI_EHIP, "probe read failed");
+    for (int i = 0; i < 6; ++i) out6[i] = (double)h[i];
     return 0;
 }
 

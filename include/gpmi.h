@@ -324,6 +324,9 @@ GPMI_API int gpmi_probe_clock(gpmi_ctx *ctx, int reset, double *out3);
 /* Fused in-block launches since the last call, block 0: cycles in the sub-tile product, in the wait for the
  * other two sub-tiles, in the diagonal-block body; number of launches; sum of their K. */
 GPMI_API int gpmi_probe_fused(gpmi_ctx *ctx, double *out5);
+/* Diagonal-block bodies (128-pivot factorisations) since the last call: shader cycles in the block loads, the 8-step
+ * loop and the stores of tile wave 0, inside factor16 and waiting for the next diagonal tile (factor wave); bodies. */
+GPMI_API int gpmi_probe_body(gpmi_ctx *ctx, double *out6);
 /* One-workgroup small-N kernels since the last call (block 0 of every launch): shader cycles in the covariance
  * build, the diagonal blocks, the rows below, number of launches, cycles in the trailing tiles, in the finalize. */
 GPMI_API int gpmi_probe_small(gpmi_ctx *ctx, double *out6);

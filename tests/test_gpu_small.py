@@ -166,12 +166,15 @@ def test_ard_grid_equals_single_ard_evaluations(ctx, orc, n, D):
     G = 40
     rng = np.random.default_rng(n + D)
     ell = 0.5 + rng.random((G, D)) * 1.5; alpha = 0.8 + 0.4 * rng.random(G); sig = 0.1 + 0.2 * rng.random(G)
-    ell[7] = 80.0; sig[7] = 1e-9      # not positive definite in fp64
+    alpha[7] = np.nan                 # a NaN amplitude: NaN covariance, "not positive definite", the others unaffected
     out, info = ctx.logml_grid_ard(X, y, alpha, ell, sig)
     assert info[7] > 0 and np.all(np.isnan(out[7])) and np.all(np.delete(info, 7) == 0)
     for g in (0, 6, 8, 31, 32, 39):
         single = ctx.logml(X, y, alpha[g], ell[g], sig[g])
-        assert tuple(out[g]) == tuple(single), (g, out[g], single)
+        if 128 < n <= 256:   # the grid runs one workgroup per point, ONE evaluation of this size the launch chain: same numbers to rounding
+            assert np.allclose(out[g], single, rtol=1e-12, atol=0), (g, out[g], single)
+        else:
+            assert tuple(out[g]) == tuple(single), (g, out[g], single)
     for g in (1, 33):
         want = orc.logml(X / ell[g], y, alpha[g], 1.0, sig[g])
         assert abs(out[g, 0] - want[0]) <= RTOL * abs(want[0])
