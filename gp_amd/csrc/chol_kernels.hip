@@ -202,7 +202,7 @@ __device__ __forceinline__ double ld_blk(const double *p)
     if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
 }
-constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 2 * 16 * 17;  // doubles of workgroup memory the body needs (52 KB)
+constexpr int DIAG4_LDS = 2 * 8 * 256 + 8 * 256 + 2 * 16 * 17 + 2;  // doubles of workgroup memory the body needs (52 KB; the last two: the tile waves' arrival counter)
 // COH: the block was written by other workgroups of the same launch with agent-scope stores; read it
 // with agent-scope loads (they do not trust this XCD's L2) instead of invalidating caches with a fence
 // FULL: the block has all 128 rows and columns (every panel but a ragged last one): the tiles below the
@@ -293,14 +293,17 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
         GPMI_LOAD_TILE(TA, ra, jb, pra)
     }
 
-#define GPMI_SOLVE_ROW(T, NJ, br, X)                                                                   \
-    if ((br) == kb) {                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) T[GPMI_CL(kb, NJ)][i] = s_d16[kb & 1][lr][lq + 4 * i]; \
-    } else if ((br) > kb) {                                                                            \
+    // step k of block-row br: the diagonal tile comes back from the factor wave as L16; a row below is solved against
+    // L16^-1 (4 chained MFMAs), keeps X as its final tile and publishes -X for the other rows' updates
+#define GPMI_SOLVE_ROW(T, NJ, br, X, k)                                                                \
+    if ((br) == (k)) {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) T[GPMI_CL(k, NJ)][i] = s_d16[(k) & 1][lr][lq + 4 * i]; \
+    } else if ((br) > (k)) {                                                                           \
+        X = d4{0.0, 0.0, 0.0, 0.0};                                                                    \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
-            X = mfma(s_inv[kb][kg * 64 + lane], T[GPMI_CL(kb, NJ)][kg], X);                            \
-        T[GPMI_CL(kb, NJ)] = X;                                                                        \
-        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) s_pub[kb & 1][br][kg * 64 + lane] = -X[kg];   \
+            X = mfma(s_inv[k][kg * 64 + lane], T[GPMI_CL(k, NJ)][kg], X);                              \
+        T[GPMI_CL(k, NJ)] = X;                                                                         \
+        _Pragma("unroll") for (int kg = 0; kg < 4; ++kg) s_pub[(k) & 1][br][kg * 64 + lane] = -X[kg];  \
     }
 
     // The only tile the next pivot block waits for is the diagonal tile of block-row kb + 1: its
@@ -341,45 +344,67 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     }
 
     GPMI_BSTAMP(b1)
+    // Between B2 (factor16 of step kb done) and B1 (the next diagonal tile handed over) -- the critical path -- ONLY the
+    // owner of block-row kb + 1 works: it solves that row (4 MFMAs), updates the next diagonal tile from its own
+    // registers (4 MFMAs) and hands it to the factor wave.  Every other solve of step kb, the publication of the -X
+    // tiles, the stores and the REST updates run behind B1, under factor16(kb + 1); the REST updates read the other
+    // rows' -X tiles, so the three tile waves meet once more in between, on an arrival counter in LDS (the factor
+    // wave, busy on the chain, takes no part).  Before: all solves of a step stood between B2 and B1 (~2.0 k cycles
+    // per step against ~0.9 k now).
+    // (explicitly an LDS pointer: through a generic one the accesses become FLAT operations, whose completion the
+    // compiler can only await with vmcnt(0) -- which would drain the block loads still in flight)
+    typedef __attribute__((address_space(3))) int lds_int;
+    lds_int *const s_cnt = (lds_int *)(sm + DIAG4_LDS - 2);
+    if (tid == 0) *s_cnt = 0;   // ordered before every arrival by the first B1
+    auto tile_waves_meet = [&](int target) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's -X tiles are in LDS
+        if (lane == 0) __hip_atomic_fetch_add(s_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
     d4 XA[8], XB[8], XC[8];
     if (rc == 0) {  // block-row 0 hands tile (0, 0) to the factor wave in matrix order
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_d16[0][lr][lq + 4 * i] = TC[0][i];
     }
-    int last = -1;  // last step whose tiles are not stored yet
+    int last = -1;  // last step whose non-critical solves and stores are still due
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         if (!FULL && kb >= nblk) break;  // workgroup-uniform
-        GPMI_LDS_BARRIER();  // B1: diagonal tile kb is in s_d16[kb & 1]; every wave's -X tiles of step kb - 1 are published
-        if (kb > 0) {     // tiles of step kb - 1 out; REST of step kb - 1: tiles jb >= kb of the rows below, except tile (kb, kb)
+        GPMI_LDS_BARRIER();  // B1: diagonal tile kb is in s_d16[kb & 1] (factor16(kb) starts)
+        if (kb > 0) {
+            // the rest of step kb - 1: its other rows' solves (row kb was solved before B1) ...
+            if (ra != kb) { GPMI_SOLVE_ROW(TA, 8, ra, XA[kb - 1], kb - 1) }
+            if (rb != kb) { GPMI_SOLVE_ROW(TB, 5, rb, XB[kb - 1], kb - 1) }
+            if (rc != kb) { GPMI_SOLVE_ROW(TC, 2, rc, XC[kb - 1], kb - 1) }
+            tile_waves_meet(3 * kb);   // ... every row's -X tile of step kb - 1 is published ...
             GPMI_STORE_STEP(TA, 8, ra, kb - 1, pra)
             GPMI_STORE_STEP(TB, 5, rb, kb - 1, prb)
             GPMI_STORE_STEP(TC, 2, rc, kb - 1, prc)
+            // ... and REST: tiles jb >= kb of the rows below, except tile (kb, kb) (updated EARLY)
             if (ra >= kb) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
             if (rb >= kb) { GPMI_UPDATE_REST(TB, 5, rb, XB[kb - 1]) }
             if (rc >= kb) { GPMI_UPDATE_REST(TC, 2, rc, XC[kb - 1]) }
         }
-        GPMI_LDS_BARRIER();  // B2: factor wave done
-        XA[kb] = d4{0.0, 0.0, 0.0, 0.0};
-        XB[kb] = XA[kb];
-        XC[kb] = XA[kb];
-        GPMI_SOLVE_ROW(TA, 8, ra, XA[kb])
-        GPMI_SOLVE_ROW(TB, 5, rb, XB[kb])
-        GPMI_SOLVE_ROW(TC, 2, rc, XC[kb])
-        if (kb < 7) {     // EARLY: the next diagonal tile (no barrier: own registers only)
-            if (ra == kb + 1) GPMI_UPDATE_EARLY(TA, 8, ra, XA[kb])
-            else if (rb == kb + 1) GPMI_UPDATE_EARLY(TB, 5, rb, XB[kb])
-            else if (rc == kb + 1) GPMI_UPDATE_EARLY(TC, 2, rc, XC[kb])
+        GPMI_LDS_BARRIER();  // B2: factor16(kb) done: L16 in s_d16[kb & 1], its inverse in s_inv[kb]
+        if (kb < 7) {     // the critical row kb + 1: solve, EARLY update of the next diagonal tile, hand-over
+            if (ra == kb + 1) { GPMI_SOLVE_ROW(TA, 8, ra, XA[kb], kb) GPMI_UPDATE_EARLY(TA, 8, ra, XA[kb]) }
+            else if (rb == kb + 1) { GPMI_SOLVE_ROW(TB, 5, rb, XB[kb], kb) GPMI_UPDATE_EARLY(TB, 5, rb, XB[kb]) }
+            else if (rc == kb + 1) { GPMI_SOLVE_ROW(TC, 2, rc, XC[kb], kb) GPMI_UPDATE_EARLY(TC, 2, rc, XC[kb]) }
         }
         last = kb;
     }
 #undef GPMI_UPDATE_EARLY
 #undef GPMI_UPDATE_REST
     GPMI_BSTAMP(b2)
-    // the last step's tiles (compile-time step index: one copy per possible last step of a ragged block)
+    // the last step: its diagonal tile back from the factor wave (rows below it are padding: nothing to solve), its stores
+    // (compile-time step index: one copy per possible last step of a ragged block)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (k == last) {
+            if (ra == k) { GPMI_SOLVE_ROW(TA, 8, ra, XA[k], k) }
+            if (rb == k) { GPMI_SOLVE_ROW(TB, 5, rb, XB[k], k) }
+            if (rc == k) { GPMI_SOLVE_ROW(TC, 2, rc, XC[k], k) }
             GPMI_STORE_STEP(TA, 8, ra, k, pra)
             GPMI_STORE_STEP(TB, 5, rb, k, prb)
             GPMI_STORE_STEP(TC, 2, rc, k, prc)
