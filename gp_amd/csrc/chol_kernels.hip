@@ -629,10 +629,10 @@ __device__ __forceinline__ void syrk_tile_bands(int c, int T, int TN, int &ti, i
 
 // One 128 x 128 output tile (ti, tj); smem is the workgroup's staging buffer (free on entry:
 // every wave has finished reading it).
-template <int MODE>
-__device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const double *__restrict__ A, size_t lda,
-                                          const double *__restrict__ B, size_t ldb, double *__restrict__ C,
-                                          size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid)
+template <int MODE, bool WHOLE>
+__device__ __forceinline__ void gemm_tile_k(double (&smem)[2][2][GK][GP], const double *__restrict__ A, size_t lda,
+                                            const double *__restrict__ B, size_t ldb, double *__restrict__ C,
+                                            size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid)
 {
     const int m0 = ti * GT, n0 = tj * GT;
     if (MODE == 1 && n0 >= N) return;
@@ -713,7 +713,7 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
         mm16(a1, b1);
     };
 
-    if (K % GK == 0 && !(dbg & 16)) {
+    if constexpr (WHOLE) {
         const double *g0 = gsrc + (size_t)krow0 * gld;
 #pragma unroll
         for (int q = 0; q < 8; ++q)  // stage 0, same lean addressing as the loop
@@ -722,30 +722,84 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
     } else {
         issue(0, 0);
     }
-    if (K % GK == 0 && !(dbg & 16)) {
+    double a0[4], b0[4];  // whole-k-step form: the fragments of sub-step 0 cross the k-step boundary
+    if constexpr (WHOLE) {
         // Whole k-steps only (every launch of a factorisation whose order is a multiple of 16): no
         // clamp, and the eight row addresses of a stage are one running per-lane pointer plus
         // loop-invariant uniform offsets -- one VALU add per DMA instead of the ~12 scalar
-        // instructions (min, 64-bit multiply, ...) of the general form, which sat between the
-        // barrier and the first fragment reads of every k-step (~100 instructions per wave)
+        // instructions (min, 64-bit multiply, ...) of the general form.
+        // The k-step boundary is software-pipelined (round 3): the barrier that publishes stage t + 1 sits BEFORE the
+        // last 16 MFMAs of step t, and the DMA of step t + 2 and the first fragment reads of step t + 1 are issued
+        // between those MFMAs -- so what a k-step exposes is the barrier itself, not barrier + DMA issue + LDS latency
+        // in front of its first MFMA (4970 cycles per 4096 of MFMA issue for a workgroup alone on a CU before).
+        // Stage t & 1 is free for the DMA of step t + 2 at that barrier: every wave has its last fragments of step t
+        // in registers (lgkmcnt(0) in front of the barrier).
         const double *gp = gsrc + (size_t)krow0 * gld;
-#pragma unroll 1
-        for (int kt = 0; kt < nk - 1; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nk > 1 && !(dbg & 2)) {
             gp += (size_t)GK * gld;
+            asm volatile("" : "+v"(gp));
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)q * gld),
+                                                 (__attribute__((address_space(3))) void *)&smem[1][op][krow0 + q][0], 16, 0, 0);
+        }
+        ldfrag(ic<0>{}, 0, 0, GK, a0, b0);
+        // one k-step that has a successor; DMA: the step after that exists and is requested here
+        auto kstep = [&](auto dma, int st) {
+            constexpr bool DMA = decltype(dma)::value != 0;
+            double a1[4], b1[4];
+            // the first reads of a1, b1 go out BEHIND the first four MFMAs: the wait in front of those then covers a0, b0
+            // only (issued a quarter of a k-step ago), not an LDS round trip
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) acc[0][tm] = mfma(a0[0], b0[tm], acc[0][tm]);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(ic<0>{}, st, 1, GK, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tn = 1; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(a0[tn], b0[tm], acc[tn][tm]);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(ic<0>{}, st, 2, GK, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm16(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(ic<0>{}, st, 3, GK, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm16(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // keep ONE running per-lane pointer (opaque to the optimiser, which otherwise turns the
             // eight invariant offsets into eight running scalar pointers: 16 SALU per k-step)
+            gp += (size_t)GK * gld;
             asm volatile("" : "+v"(gp));
-            compute(ic<0>{}, kt & 1, GK, [&]() {
-                if (!(dbg & 2)) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
+            for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(a1[tn], b1[tm], acc[tn][tm]);
+                __builtin_amdgcn_sched_barrier(0);
+                a0[tn] = smem[st ^ 1][1][lq][wn * 64 + tn * 16 + lr];
+                b0[tn] = smem[st ^ 1][0][lq][wm * 64 + tn * 16 + lr];
+                if constexpr (DMA) if (tn < 2) {  // all eight requests behind the first eight MFMAs: they have until the next barrier
+#pragma unroll
+                    for (int q = 4 * tn; q < 4 * tn + 4; ++q)
                         __builtin_amdgcn_global_load_lds(
                             (const __attribute__((address_space(1))) void *)(gp + (size_t)q * gld),
-                            (__attribute__((address_space(3))) void *)&smem[(kt + 1) & 1][op][krow0 + q][0], 16, 0, 0);
+                            (__attribute__((address_space(3))) void *)&smem[st][op][krow0 + q][0], 16, 0, 0);
                 }
-            });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (dbg & 2) {
+#pragma unroll 1
+            for (int kt = 0; kt < nk - 1; ++kt) kstep(ic<0>{}, kt & 1);
+        } else {
+#pragma unroll 1
+            for (int kt = 0; kt < nk - 2; ++kt) kstep(ic<1>{}, kt & 1);
+            if (nk > 1) kstep(ic<0>{}, nk & 1);  // step nk - 2: nothing left to request
         }
     } else {
 #pragma unroll 1
@@ -767,8 +821,10 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
     double *const cbase = C + (size_t)(m0 + wm * 64 + lr) + (size_t)(n0 + wn * 64 + lq) * ldc;
     double ch[2][4][4];
     const bool cnt = (dbg & 8) != 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (!WHOLE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (MODE != 2 && interior) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
@@ -777,7 +833,31 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ch[tn][tm][i] = ld_c(cbase + tm * 16 + (size_t)(tn * 16 + 4 * i) * ldc, cnt);
     }
-    compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK, []() {});
+    if constexpr (WHOLE) {  // the fragments of sub-step 0 of the last stage are in registers
+        const int st = (nk - 1) & 1;
+        double a1[4], b1[4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[0][tm] = mfma(a0[0], b0[tm], acc[0][tm]);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(ic<0>{}, st, 1, GK, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tn = 1; tn < 4; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = mfma(a0[tn], b0[tm], acc[tn][tm]);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(ic<0>{}, st, 2, GK, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm16(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(ic<0>{}, st, 3, GK, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm16(a0, b0);
+        mm16(a1, b1);
+    } else {
+        compute(ic<1>{}, (nk - 1) & 1, K - (nk - 1) * GK, []() {});
+    }
     if (dbg & 1) {
         double sacc = 0.0;
 #pragma unroll
@@ -840,6 +920,18 @@ __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const do
                     C[(size_t)m + (size_t)n * ldc] = (MODE == 2) ? acc[tn][tm][i] : ce[tm][i] - acc[tn][tm][i];
             }
     }
+}
+
+
+// Whole k-steps (every launch of a factorisation whose order is a multiple of 16) take the software-pipelined form;
+// the two forms are separate instantiations so that neither's live ranges weigh on the other's register allocation.
+template <int MODE>
+__device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const double *__restrict__ A, size_t lda,
+                                          const double *__restrict__ B, size_t ldb, double *__restrict__ C,
+                                          size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid)
+{
+    if (K % GK == 0 && !(dbg & 16)) gemm_tile_k<MODE, true>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, tid);  // workgroup-uniform
+    else gemm_tile_k<MODE, false>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, tid);
 }
 
 
