@@ -1707,6 +1707,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm9(const double *__restrict__ A, 
 #define GPMI_STAMP(v)
 #define GPMI_STAMP_ADD(i, d)
 #endif
+constexpr int FIN_SLICE = 256;  // slice of the diagonal one workgroup of k_logml_partial reduces
 struct SmallSe {            // hyper-parameters of one point, in registers
     double a2;
     double inv_ell[GPMI_MAXD];
@@ -1875,23 +1876,48 @@ __device__ __forceinline__ void logml_small_body(double (&smem)[2][2][GK][GP], d
     GPMI_STAMP_ADD(3, 1)
     small_potrf_partial(smem, s_F, s_aux, W, ld, n + 1, n, n, info_w, true);
     GPMI_STAMP(tb2)
-    // sum log L_ii, z'z: the reduction tree of k_logml_partial / k_logml_finalize (n <= 256: one slice)
-    double a = 0.0, b = 0.0;
-    if (tid < n) {
-        a = log(W[(size_t)tid * (ld + 1)]);
-        const double z = W[(size_t)n + (size_t)tid * ld];
-        b = z * z;
-    }
+    // sum log L_ii, z'z: the reduction tree of k_logml_partial (slices of 256, thread `slice` keeps its sum) and, for more
+    // than one slice, of k_logml_finalize over the slice sums -- the same additions in the same order as the blocked path
     double *s_a = s_aux, *s_b = s_aux + 256;
-    s_a[tid] = a;
-    s_b[tid] = b;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st) {
-            s_a[tid] += s_a[tid + st];
-            s_b[tid] += s_b[tid + st];
+    const int nslice = (n + FIN_SLICE - 1) / FIN_SLICE;
+    double pa = 0.0, pb = 0.0;
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int i = sl * FIN_SLICE + tid;
+        double a = 0.0, b = 0.0;
+        if (i < n) {
+            a = log(W[(size_t)i * (ld + 1)]);
+            const double z = W[(size_t)n + (size_t)i * ld];
+            b = z * z;
         }
+        s_a[tid] = a;
+        s_b[tid] = b;
         __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                s_a[tid] += s_a[tid + st];
+                s_b[tid] += s_b[tid + st];
+            }
+            __syncthreads();
+        }
+        if (nslice > 1) {
+            if (tid == sl) {
+                pa = s_a[0];
+                pb = s_b[0];
+            }
+            __syncthreads();
+        }
+    }
+    if (nslice > 1) {
+        s_a[tid] = pa;
+        s_b[tid] = pb;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                s_a[tid] += s_a[tid + st];
+                s_b[tid] += s_b[tid + st];
+            }
+            __syncthreads();
+        }
     }
     if (tid == 0) {
         const int info = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1992,6 +2018,38 @@ __global__ __launch_bounds__(256, 2) void k_logml_small_batch_ard(const double *
     for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = b.inv_ell[g][d];
     logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, b.diag[g], Wall + (size_t)g * wstride, ld, out3 + 3 * (size_t)g,
                      info_out + g, info_w + g, ec);
+}
+
+// Points whose hyper-parameters lie in DEVICE memory -- any number per launch, isotropic or ARD: par[g] = {alpha^2,
+// sigma^2 + jitter, 1 / ell_0 .. 1 / ell_7}.  Used for grids of more than GPMI_SMALL_PTS points and for the mid sizes
+// (n <= 1024) at which a grid large enough to give every CU a problem of its own beats the four lanes of the blocked path.
+constexpr int SMALL_PAR = 2 + GPMI_MAXD;
+__global__ __launch_bounds__(256, 2) void k_logml_small_batch_dev(const double *__restrict__ X, int n, int ldx, int D,
+                                                               const double *__restrict__ y, const double *__restrict__ par,
+                                                               double *__restrict__ Wall, size_t wstride, size_t ld,
+                                                               double *__restrict__ out3, int *info_out, int *info_w, ExpC ec)
+{
+    GPMI_SMALL_LDS
+    const int g = blockIdx.x;
+    const double *pg = par + (size_t)g * SMALL_PAR;
+    SmallSe se;
+    se.a2 = pg[0];
+    se.D = D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = pg[2 + d];
+    logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, pg[1], Wall + (size_t)g * wstride, ld, out3 + 3 * (size_t)g,
+                     info_out + g, info_w + g, ec);
+}
+
+// stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
+// have to be fenced against an earlier asynchronous call)
+constexpr int PUT_MAX = 480;
+struct PutArgs {
+    double v[PUT_MAX];
+};
+__global__ __launch_bounds__(256) void k_put_doubles(PutArgs a, double *__restrict__ dst, int count)
+{
+    for (int i = threadIdx.x; i < count; i += 256) dst[i] = a.v[i];
 }
 
 // the factorisation alone (launch_potrf_partial at small sizes: posteriors, rbf_cov_chol, ...)
@@ -2165,7 +2223,6 @@ __global__ void k_get_row(const double *__restrict__ W, size_t ld, int row, int 
 // not depend on timing): FIN_WG workgroups reduce 256-element slices of the diagonal -- every L_ii
 // sits in a cache line of its own, so the loads want many waves in flight; one workgroup doing all of
 // them took 60 us at N = 16384 -- and a last workgroup adds the slice sums in slice order.
-constexpr int FIN_SLICE = 256;
 __global__ __launch_bounds__(FIN_SLICE) void k_logml_partial(const double *__restrict__ W, size_t ld, int n, int zrow,
                                                              double *__restrict__ part)
 {
@@ -2304,6 +2361,7 @@ static void small_lds_attr()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_ard), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_dev), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done[dev] = true;
 }
@@ -2327,6 +2385,8 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->small_n = 256;
     t->small_n1 = 128;
     t->small_m = 160;
+    t->small_n2 = 1024;
+    t->small_g2 = 40;
 }
 
 void launch_gemm_nt(const gpmi_ctx *c, hipStream_t s, const double *A, size_t lda, const double *B, size_t ldb,
@@ -2899,6 +2959,32 @@ void launch_logml_small_batch_ard(hipStream_t s, const double *dX, int n, int ld
     small_ws_layout(n, &ld, &stride);
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_small_batch_ard, dim3(G), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall,
+                       stride, ld, d_out3, d_info_out, d_info_work, h_exp);
+}
+
+// G points (any number) whose parameters are uploaded to d_par (G * (2 + GPMI_MAXD) doubles) in stream order; ell: one
+// length-scale per point (n_ell == 1) or D per point (point-major); Wall: G slices (small_ws_layout)
+void launch_logml_small_batch_dev(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                                  const double *ell, int n_ell, const double *sigma, int G, double jitter, double *d_par,
+                                  double *Wall, double *d_out3, int *d_info_out, int *d_info_work)
+{
+    static_assert(PUT_MAX % SMALL_PAR == 0, "whole points per upload");
+    PutArgs a;
+    for (int g0 = 0; g0 < G; g0 += PUT_MAX / SMALL_PAR) {
+        const int gc = (G - g0 < PUT_MAX / SMALL_PAR) ? G - g0 : PUT_MAX / SMALL_PAR;
+        for (int g = 0; g < gc; ++g) {
+            double *q = a.v + g * SMALL_PAR;
+            q[0] = alpha[g0 + g] * alpha[g0 + g];
+            q[1] = sigma[g0 + g] * sigma[g0 + g] + jitter;
+            for (int d = 0; d < GPMI_MAXD; ++d)
+                q[2 + d] = d < D ? 1.0 / (n_ell == 1 ? ell[g0 + g] : ell[(size_t)(g0 + g) * D + d]) : 0.0;
+        }
+        hipLaunchKernelGGL(k_put_doubles, dim3(1), 256, 0, s, a, d_par + (size_t)g0 * SMALL_PAR, gc * SMALL_PAR);
+    }
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_logml_small_batch_dev, dim3(G), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, d_par, Wall,
                        stride, ld, d_out3, d_info_out, d_info_work, h_exp);
 }
 

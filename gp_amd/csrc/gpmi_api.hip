@@ -304,6 +304,8 @@ extern "C" int gpmi_destroy(gpmi_ctx *c)
         if (c->d_info) (void)hipFree(c->d_info);
         if (c->d_ctr) (void)hipFree(c->d_ctr);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
+        if (c->d_spar) (void)hipFree(c->d_spar);
+        if (c->d_sinfo) (void)hipFree(c->d_sinfo);
         free(c->itp_lp);
         if (c->ktimer) {  // per-kernel timing events (gpmi_set_option "kernel_timing")
             KTimer *k = (KTimer *)c->ktimer;
@@ -402,6 +404,16 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
 #endif
         if (value != 0 && value != 2) return gpmi_fail(GPMI_EARG, "syrk_order must be 0 (row-major) or 2 (XCD bands)");
         c->tune.syrk_order = value;
+        return 0;
+    }
+    if (!strcmp(name, "small_n2")) {  // ... up to this n for grids of at least small_g2 (n / 1024)^2 + 2 points (0: off)
+        if (value < 0 || value > GPMI_SMALL_NMAX) return gpmi_fail(GPMI_EARG, "small_n2 must be 0 .. %d", GPMI_SMALL_NMAX);
+        c->tune.small_n2 = value;
+        return 0;
+    }
+    if (!strcmp(name, "small_g2")) {
+        if (value < 0) return gpmi_fail(GPMI_EARG, "small_g2 must be >= 0");
+        c->tune.small_g2 = value;
         return 0;
     }
     if (!strcmp(name, "small_n")) {  // one-workgroup marginal likelihood up to this n (0: off, <= 256)
@@ -862,8 +874,64 @@ static bool small_logml(const gpmi_ctx *c, int n, int D, int G = 1)
 {
     // one workgroup against the multi-CU launch chain (tools/small_n_bench.py, one evaluation / 64 points, us per
     // evaluation): n = 21: 20 vs 36 / 0.6 vs 22; 128: 43 vs 43 / 1.0 vs 23; 199: 118 vs 89 / 2.2 vs 33; 256: 145 vs 79 / 2.6 vs 30
-    const int lim = (G >= 6 || c->tune.small_n1 > c->tune.small_n) ? c->tune.small_n : c->tune.small_n1;
-    return lim > 0 && n <= lim && D <= GPMI_MAXD;
+    int lim = (G >= 6 || c->tune.small_n1 > c->tune.small_n) ? c->tune.small_n : c->tune.small_n1;
+    // larger grids at mid sizes: a workgroup needs n^3 time, but G of them run side by side on CUs of their own, the
+    // four lanes of the blocked path one point after another at ~36 us per 128-column panel
+    // (tools/mid_n_grid_bench.py: one workgroup takes 0.21 / 0.59 / 1.55 / 3.1 ms at n = 300 / 512 / 768 / 1024 whatever
+    // the number of points up to 256, the lanes 54 / 60 / 85 / 109 us PER POINT: break-even at G = 5 / 12 / 24 / 38,
+    // i.e. about small_g2 (n / 1024)^2 + 2 points with small_g2 = 40)
+    if (lim > 0 && n > lim && n <= c->tune.small_n2) {
+        const double r = (double)n / 1024.0;
+        if ((double)G >= (double)c->tune.small_g2 * r * r + 2.0) lim = c->tune.small_n2;
+    }
+    return lim > 0 && n <= lim && n <= GPMI_SMALL_NMAX && D <= GPMI_MAXD;
+}
+
+static int reserve_ws_small(gpmi_ctx *c, int n, int count);
+
+// device buffers of the device-parameter small-N grid: parameters and one work int per point
+static int reserve_small_par(gpmi_ctx *c, int G)
+{
+    if (G <= c->spar_pts) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_spar) HIPCHK(hipFree(c->d_spar));
+    if (c->d_sinfo) HIPCHK(hipFree(c->d_sinfo));
+    c->d_spar = nullptr;
+    c->d_sinfo = nullptr;
+    c->spar_pts = 0;
+    const int cap = G < 1024 ? 1024 : G;
+    if (hipMalloc((void **)&c->d_spar, (size_t)cap * GPMI_SMALL_PAR * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&c->d_sinfo, (size_t)cap * sizeof(int)) != hipSuccess)
+        return gpmi_fail(GPMI_ENOMEM, "cannot allocate the parameter buffers of a %d-point grid", G);
+    c->spar_pts = cap;
+    return 0;
+}
+
+// G points by one workgroup each: up to `per_args` of them per launch with the parameters as kernel arguments (lowest
+// latency), larger grids and n > 256 through the device-parameter form (any number per launch, GPMI_SMALL_DEV_PTS
+// workspace slices at a time)
+static int small_grid(gpmi_ctx *c, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                      const double *ell, int n_ell, const double *sigma, int G, double jitter, double *d_out3, int *d_info)
+{
+    int rc;
+    const int per_args = n_ell == 1 ? GPMI_SMALL_PTS : GPMI_SMALL_PTS_ARD;
+    if (G <= per_args && n <= 256) {
+        if ((rc = reserve_ws_small(c, n, G))) return rc;
+        if (n_ell == 1) launch_logml_small_batch(c->stream, dX, n, ldx, D, dy, alpha, ell, sigma, G, jitter, c->W, d_out3, d_info, c->d_ctr + 64);
+        else launch_logml_small_batch_ard(c->stream, dX, n, ldx, D, dy, alpha, ell, sigma, G, jitter, c->W, d_out3, d_info, c->d_ctr + 64);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const int per = G < GPMI_SMALL_DEV_PTS ? G : GPMI_SMALL_DEV_PTS;
+    if ((rc = reserve_ws_small(c, n, per))) return rc;
+    if ((rc = reserve_small_par(c, per))) return rc;
+    for (int g0 = 0; g0 < G; g0 += per) {
+        const int gc = (G - g0 < per) ? G - g0 : per;
+        launch_logml_small_batch_dev(c->stream, dX, n, ldx, D, dy, alpha + g0, ell + (size_t)g0 * (n_ell == 1 ? 1 : D), n_ell,
+                                     sigma + g0, gc, jitter, c->d_spar, c->W, d_out3 + 3 * (size_t)g0, d_info + g0, c->d_sinfo);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // workspace for `count` slices of the small-N kernel
@@ -944,16 +1012,7 @@ extern "C" int gpmi_logml_grid_dev(gpmi_ctx *c, const double *dX, int n, int ldx
         // travel as kernel arguments), no lanes, no per-point launch chain
         for (int g = 0; g < G; ++g)
             if (!(rho[g] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
-        const int per = G < GPMI_SMALL_PTS ? G : GPMI_SMALL_PTS;
-        int rc = reserve_ws_small(c, n, per);
-        if (rc) return rc;
-        for (int g0 = 0; g0 < G; g0 += GPMI_SMALL_PTS) {
-            const int gc = (G - g0 < GPMI_SMALL_PTS) ? G - g0 : GPMI_SMALL_PTS;
-            launch_logml_small_batch(c->stream, dX, n, ldx, D, dy, alpha + g0, rho + g0, sigma + g0, gc, jitter, c->W,
-                                     d_out3 + 3 * (size_t)g0, d_info + g0, c->d_ctr + 64);
-        }
-        HIPCHK(hipGetLastError());
-        return 0;
+        return small_grid(c, dX, n, ldx, D, dy, alpha, rho, 1, sigma, G, jitter, d_out3, d_info);
     }
     // Independent points fan out over `lanes` internal contexts (own workspaces and streams):
     // while one point is in its latency-bound panel phase or in the tail of a trailing update,
@@ -996,15 +1055,7 @@ extern "C" int gpmi_logml_grid_ard_dev(gpmi_ctx *c, const double *dX, int n, int
     for (int g = 0; g < G; ++g)
         if ((rc = fill_params(&ps[g], D, alpha[g], ell + (size_t)g * D, D))) return rc;
     if (small_logml(c, n, D, G)) {
-        const int per = G < GPMI_SMALL_PTS_ARD ? G : GPMI_SMALL_PTS_ARD;
-        if ((rc = reserve_ws_small(c, n, per))) return rc;
-        for (int g0 = 0; g0 < G; g0 += GPMI_SMALL_PTS_ARD) {
-            const int gc = (G - g0 < GPMI_SMALL_PTS_ARD) ? G - g0 : GPMI_SMALL_PTS_ARD;
-            launch_logml_small_batch_ard(c->stream, dX, n, ldx, D, dy, alpha + g0, ell + (size_t)g0 * D, sigma + g0, gc, jitter,
-                                         c->W, d_out3 + 3 * (size_t)g0, d_info + g0, c->d_ctr + 64);
-        }
-        HIPCHK(hipGetLastError());
-        return 0;
+        return small_grid(c, dX, n, ldx, D, dy, alpha, ell, D, sigma, G, jitter, d_out3, d_info);
     }
     int lanes = c->grid_lanes > 0 ? c->grid_lanes : (G % 4 == 0 ? 4 : (G % 3 == 0 ? 3 : 4));
     if (lanes > 8) lanes = 8;

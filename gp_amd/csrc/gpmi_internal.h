@@ -36,6 +36,7 @@ struct gpmi_tuning {
     int small_n;          // grids of marginal likelihoods at n <= small_n (and D <= GPMI_MAXD): one workgroup per point, one launch (0: off)
     int small_n1;         // ... a single evaluation (or a grid of fewer than 6 points) up to this n: beyond it the multi-CU launch chain is faster
     int small_m;          // partial factorisation of <= small_m rows: one workgroup, one launch (0: off)
+    int small_n2, small_g2;  // grids of >= small_g2 (n / 1024)^2 + 2 points: one workgroup per point up to n <= small_n2 (every CU a problem of its own)
 };
 void gpmi_tuning_defaults(gpmi_tuning *t);
 
@@ -61,6 +62,9 @@ struct gpmi_ctx {
     double *h_pin;           // pinned, device-mapped host buffer: inputs and results of small host-buffer calls travel without a copy call
     double *h_pin_dev;       // its device address
     size_t h_pin_bytes;
+    double *d_spar;          // device-parameter small-N grids: GPMI_SMALL_PAR doubles + one work int per point
+    int *d_sinfo;
+    int spar_pts;            // capacity (points)
     // generic device staging buffers for the host-pointer API
     double *stage[4];
     size_t stage_bytes[4];
@@ -164,6 +168,13 @@ void launch_logml_small_batch_ard(hipStream_t s, const double *dX, int n, int ld
 void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                               const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_out3,
                               int *d_info_out, int *d_info_work);
+// any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
+#define GPMI_SMALL_PAR (2 + GPMI_MAXD)
+#define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS
+#define GPMI_SMALL_DEV_PTS 512 // points per launch of the device-parameter form (workspace slices held at a time)
+void launch_logml_small_batch_dev(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                                  const double *ell, int n_ell, const double *sigma, int G, double jitter, double *d_par,
+                                  double *Wall, double *d_out3, int *d_info_out, int *d_info_work);
 // inverses of L's 128 x 128 diagonal blocks (ceil(n / 128) x 128 x 128 doubles, tmp the same) from packed factors
 void launch_diag_inverses(hipStream_t s, const double *Fpack_all, int n, double *Dinv, double *tmp);
 // t = L^-1 k for ONE right-hand side in one launch (k_trsv_wave); k and t are different buffers of n doubles
