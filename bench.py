@@ -181,13 +181,14 @@ def c1_record(ctx, dev, skip_cpu):
     rec = {"workload": "c1 and the reference's own sizes: one host-buffer gpmi_logml call; 64-point (rho x sigma) grid through "
                        "gpmi_logml_grid_dev (one workgroup per point, one launch)", "sizes": []}
     ctx.set_stream(None)
-    for n in (21, 199, 256):
+    for n in (21, 199, 256, 512, 1024):   # 512, 1024: the grid runs one workgroup per point with the parameters in device memory
         x = np.linspace(0.0, 10.0, n).reshape(-1, 1); y = np.sin(x[:, 0])
         ctx.logml(x, y, 1.0, [1.0], 0.1)
         t0 = time.perf_counter()
-        for _ in range(200):
+        calls = 200 if n <= 256 else 40
+        for _ in range(calls):
             val = ctx.logml(x, y, 1.0, [1.0], 0.1)[0]
-        host_us = 1e6 * (time.perf_counter() - t0) / 200
+        host_us = 1e6 * (time.perf_counter() - t0) / calls
         dx = torch.from_numpy(x[:, 0].copy()).to(dev); dy = torch.from_numpy(y).to(dev)
         G = 64
         out = torch.zeros((G, 3), dtype=torch.float64, device=dev); info = torch.zeros(G, dtype=torch.int32, device=dev)
@@ -206,7 +207,7 @@ def c1_record(ctx, dev, skip_cpu):
             from oracle import oracle as orc
             orc.logml(x, y, 1.0, 1.0, 0.1)
             t0 = time.perf_counter()
-            reps = 20 if n > 100 else 200
+            reps = 200 if n <= 100 else (20 if n <= 256 else 2)
             for _ in range(reps):
                 want = orc.logml(x, y, 1.0, 1.0, 0.1)[0]
             e["cpu_oracle_1_thread_us"] = 1e6 * (time.perf_counter() - t0) / reps
