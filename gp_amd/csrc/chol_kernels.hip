@@ -442,9 +442,11 @@ __global__ __launch_bounds__(256, 2) void k_potrf_diag4(double *__restrict__ A, 
 // ---------------------------------------------------------------------------
 // FULL: all 64 rows of the workgroup and all 128 columns exist -- unconditional, batched loads and
 // stores from one running column pointer (the guarded form predicates and branches per element)
+// kb0 (wave-uniform): the strip's columns left of block kb0 are zero (rows of the identity / of an upper-triangular
+// operand): those block steps produce zeros and are skipped
 template <bool FULL>
 __device__ __forceinline__ void trsm_panel_body(const double *__restrict__ s_F, double *__restrict__ Acol, size_t lda,
-                                                int r, bool rok, int nb_act, int tid = (int)threadIdx.x)
+                                                int r, bool rok, int nb_act, int tid = (int)threadIdx.x, int kb0 = 0)
 {
     const int lane = tid & 63;
     const int lq = lane >> 4;
@@ -473,7 +475,7 @@ __device__ __forceinline__ void trsm_panel_body(const double *__restrict__ s_F, 
 
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        if (kb < nblk) {
+        if (kb >= kb0 && kb < nblk) {
             d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) acc = mfma(s_F[fp_inv(kb) * 256 + kg * 64 + lane], T[kb][kg], acc);
@@ -629,10 +631,29 @@ __device__ __forceinline__ void syrk_tile_bands(int c, int T, int TN, int &ti, i
 
 // One 128 x 128 output tile (ti, tj); smem is the workgroup's staging buffer (free on entry:
 // every wave has finished reading it).
-template <int MODE, bool WHOLE>
+// MODE 3: the product A B^T is not stored, its elements are consumed where they are (the accumulators never leave their
+// registers; C is unused): epi.row(tm, m, ok) announces the lane's four rows, then per column epi.col(n, ok) and
+// epi.elem(v, tm) for its four elements -- so that the consumer loads what depends on a row or a column once.
+struct NoEpi {
+    __device__ void row(int, int, bool) const {}
+    __device__ void col(int, bool) const {}
+    __device__ void elem(double, int) const {}
+};
+template <class R, class C, class E>
+struct Epi3 {
+    R row;
+    C col;
+    E elem;
+};
+template <class R, class C, class E>
+__device__ __forceinline__ Epi3<R, C, E> make_epi3(R r, C c, E e)
+{
+    return Epi3<R, C, E>{r, c, e};
+}
+template <int MODE, bool WHOLE, class EPI = NoEpi>
 __device__ __forceinline__ void gemm_tile_k(double (&smem)[2][2][GK][GP], const double *__restrict__ A, size_t lda,
                                             const double *__restrict__ B, size_t ldb, double *__restrict__ C,
-                                            size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid)
+                                            size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid, EPI &&epi = EPI{})
 {
     const int m0 = ti * GT, n0 = tj * GT;
     if (MODE == 1 && n0 >= N) return;
@@ -825,7 +846,7 @@ __device__ __forceinline__ void gemm_tile_k(double (&smem)[2][2][GK][GP], const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (MODE != 2 && interior) {
+    if (MODE != 2 && MODE != 3 && interior) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -867,6 +888,23 @@ __device__ __forceinline__ void gemm_tile_k(double (&smem)[2][2][GK][GP], const 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sacc += acc[tn][tm][i];
         if (sacc == 1.2345e300) cbase[0] = sacc;
+        return;
+    }
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int m = m0 + wm * 64 + tm * 16 + lr;
+            epi.row(tm, m, m < M);
+        }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + tn * 16 + lq + 4 * i;
+                epi.col(n, n < N);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) epi.elem(acc[tn][tm][i], tm);
+            }
         return;
     }
     if (interior) {
@@ -925,13 +963,13 @@ __device__ __forceinline__ void gemm_tile_k(double (&smem)[2][2][GK][GP], const 
 
 // Whole k-steps (every launch of a factorisation whose order is a multiple of 16) take the software-pipelined form;
 // the two forms are separate instantiations so that neither's live ranges weigh on the other's register allocation.
-template <int MODE>
+template <int MODE, class EPI = NoEpi>
 __device__ __forceinline__ void gemm_tile(double (&smem)[2][2][GK][GP], const double *__restrict__ A, size_t lda,
                                           const double *__restrict__ B, size_t ldb, double *__restrict__ C,
-                                          size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid)
+                                          size_t ldc, int M, int N, int K, int ti, int tj, int dbg, int tid, EPI &&epi = EPI{})
 {
-    if (K % GK == 0 && !(dbg & 16)) gemm_tile_k<MODE, true>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, tid);  // workgroup-uniform
-    else gemm_tile_k<MODE, false>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, tid);
+    if (K % GK == 0 && !(dbg & 16)) gemm_tile_k<MODE, true>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, tid, epi);  // workgroup-uniform
+    else gemm_tile_k<MODE, false>(smem, A, lda, B, ldb, C, ldc, M, N, K, ti, tj, dbg, tid, epi);
 }
 
 
@@ -1766,9 +1804,14 @@ __device__ __forceinline__ void small_row_solve(const double *__restrict__ s_F, 
 // Right-looking partial factorisation by ONE workgroup: the first nfac columns of the M x ncol lower trapezoid in
 // W are factored, rows below / the trailing block updated (launch_potrf_partial's contract).  one_row: the caller
 // promises M == ncol + 1 == nfac + 1 (one augmented row), which lets the last panel use small_row_solve.
+// WITH_U (value + gradient kernels): U (same leading dimension, holds the identity on entry) becomes L^-T, block column
+// by block column while that panel's packed factors are in LDS: column block k of U holds I - sum_{j < k} U[:, j] L[k, j]^T
+// in its rows [0, k + nb) when panel k has been factored; the panel's strips apply L_kk^-T, and the panel's rows below
+// (solved next) take the block out of the later column blocks in one product each.
+template <bool WITH_U = false>
 __device__ __forceinline__ void small_potrf_partial(double (&smem)[2][2][GK][GP], double *__restrict__ s_F,
                                                     double *__restrict__ s_aux, double *__restrict__ W, size_t ld, int M,
-                                                    int ncol, int nfac, int *info, bool one_row)
+                                                    int ncol, int nfac, int *info, bool one_row, double *__restrict__ U = nullptr)
 {
     const size_t ld0 = ld;
     // thread index, re-read behind an optimisation barrier in front of every phase: everything a phase derives from it
@@ -1794,6 +1837,18 @@ __device__ __forceinline__ void small_potrf_partial(double (&smem)[2][2][GK][GP]
         __syncthreads();
         GPMI_STAMP(ts1)
         GPMI_STAMP_ADD(1, ts1 - ts0)
+        if constexpr (WITH_U) {
+            for (int rb = 0; rb < k + nb; rb += 64) {
+                const int tid = fresh_tid();
+                const int r = rb + (tid >> 6) * 16 + (tid & 15);
+                // rows inside this panel are rows of the identity: zero left of their own 16-column block
+                const int rw = rb + (tid >> 6) * 16 - k;
+                const int kb0 = __builtin_amdgcn_readfirstlane(rw > 0 ? rw >> 4 : 0);
+                if (nb == GPMI_NB && rb + 64 <= k + nb) trsm_panel_body<true>(s_F, U + (size_t)k * ld, ld, r, true, nb, tid, kb0);
+                else trsm_panel_body<false>(s_F, U + (size_t)k * ld, ld, r, r < k + nb, nb, tid, kb0);
+            }
+            __syncthreads();
+        }
         const int r0 = k + nb;
         if (r0 >= M) break;
         if (one_row && M - r0 == 1) {
@@ -1815,6 +1870,16 @@ __device__ __forceinline__ void small_potrf_partial(double (&smem)[2][2][GK][GP]
         GPMI_STAMP_ADD(2, ts2 - ts1)
         // trailing block: C[r0.., r0..ncol) -= X X^T, lower tiles
         const int mt = M - r0, nt = ncol - r0;
+        if constexpr (WITH_U) {
+            if (nt > 0) {  // U[0 : r0, r0 : ncol) -= U[0 : r0, k : r0) L[r0 : ncol, k : r0)^T
+                for (int ti = 0; ti * GT < r0; ++ti)
+                    for (int tj = 0; tj * GT < nt; ++tj) {
+                        gemm_tile<0>(smem, U + (size_t)k * ld, ld, W + (size_t)r0 + (size_t)k * ld, ld, U + (size_t)r0 * ld, ld, r0, nt,
+                                     nb, ti, tj, 0, fresh_tid());
+                        __syncthreads();
+                    }
+            }
+        }
         if (nt <= 0) continue;
         const double *X = W + (size_t)r0 + (size_t)k * ld;
         double *C = W + (size_t)r0 + (size_t)r0 * ld;
@@ -1934,6 +1999,208 @@ __device__ __forceinline__ void logml_small_body(double (&smem)[2][2][GK][GP], d
     GPMI_STAMP_ADD(5, tb3 - tb2)
 }
 
+// Value AND gradient sums of models/fit_hyperparameters.stan:18-32 by ONE workgroup (n <= 256, D <= GPMI_MAXD): what one
+// leapfrog step of NUTS asks for at the sizes the reference's fits run (R/tests.R:5 N = 21, pendulum_fit.R 79 .. 199), where
+// the launch chain of gpmi_logml_grad (factorisation, identity, L^-T, K^-1, contraction: ~25 launches + 4 copies) costs 150 us.
+// d logml / d theta = 1/2 tr((a a' - K^-1) dK/dtheta): U = L^-T rides along in the factorisation (small_potrf_partial<true>),
+// a = U z, K^-1 = U U^T by gemm_tile<2> over the lower tiles (only the columns >= the tile row's first: U is upper
+// triangular), and the contraction re-evaluates the kernel from the scaled coordinates in LDS, thread = row.
+// res: [0..2] logml, sum log L_ii, z'z; [3 + s] the contraction sums in the layout of k_grad_partial (GRAD_NS = 10 slots:
+// [0] sum c, [1 + d] sum c (x_id - x_jd)^2, [9] sum_i g_ii) -- the host turns them into the gradient as for the chain.
+constexpr int SMALL_GRAD_NS = 2 + GPMI_MAXD, SMALL_GRAD_RES = 3 + SMALL_GRAD_NS;
+__device__ __forceinline__ void logml_grad_small_body(double (&smem)[2][2][GK][GP], double *__restrict__ s_F, double *__restrict__ s_aux,
+                                                      const double *__restrict__ X, int n, int ldx, const double *__restrict__ y,
+                                                      const SmallSe &se, double diag_add, double *__restrict__ W, size_t ld,
+                                                      double *__restrict__ U, double *__restrict__ res, int *info_out, int *info_w,
+                                                      const ExpC &ec)
+{
+    const int tid = threadIdx.x;
+    GPMI_STAMP(tg0)
+    if (tid == 0) *info_w = 0;
+    double *xs = &smem[0][0][0][0];
+    auto stage_x = [&]() {
+#pragma unroll
+        for (int d = 0; d < GPMI_MAXD; ++d)
+            if (d < se.D)
+                for (int i = tid; i < n; i += 256) xs[i + d * n] = __dmul_rn(X[(size_t)i + (size_t)d * ldx], se.inv_ell[d]);
+        __syncthreads();
+    };
+    stage_x();
+    for (int row0 = 0; row0 < n; row0 += SE_TR)
+        for (int col0 = 0; col0 < row0 + SE_TR && col0 < n; col0 += SE_TC) {
+            switch (se.D) {
+            case 1: se_cov_tile<1, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+            case 2: se_cov_tile<2, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+            case 3: se_cov_tile<3, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+            default: se_cov_tile<0, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+            }
+        }
+    for (int j = tid; j < n; j += 256) W[(size_t)n + (size_t)j * ld] = y[j];
+    {   // U = I: 16-byte stores (row pair of a thread; ld is even and the slice 16-byte aligned), then the diagonal
+        const int rp = 2 * (tid & 127), cp = tid >> 7;
+        if (rp < n)
+            for (int j = cp; j < n; j += 2) *reinterpret_cast<double2 *>(U + (size_t)rp + (size_t)j * ld) = make_double2(0.0, 0.0);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) U[(size_t)i * (ld + 1)] = 1.0;
+    }
+    __syncthreads();
+    GPMI_STAMP(tg1)
+    GPMI_STAMP_ADD(0, tg1 - tg0)
+    GPMI_STAMP_ADD(3, 1)
+    small_potrf_partial<true>(smem, s_F, s_aux, W, ld, n + 1, n, n, info_w, true, U);
+    __syncthreads();
+    GPMI_STAMP(tg2)
+    // value: one slice (n <= 256), the tree of k_logml_partial
+    double *s_a = s_aux, *s_b = s_aux + 256, *s_z = s_aux + 512, *s_av = s_aux + 768;
+    {
+        double a = 0.0, b = 0.0, z = 0.0;
+        if (tid < n) {
+            a = log(W[(size_t)tid * (ld + 1)]);
+            z = W[(size_t)n + (size_t)tid * ld];
+            b = z * z;
+        }
+        s_a[tid] = a;
+        s_b[tid] = b;
+        s_z[tid] = z;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                s_a[tid] += s_a[tid + st];
+                s_b[tid] += s_b[tid + st];
+            }
+            __syncthreads();
+        }
+    }
+    const double sum_log = s_a[0], zz = s_b[0];
+    // a = U z = K^-1 y (U upper triangular: the columns left of a wave's first row are zero); sixteen loads in flight per
+    // round trip -- a loop with one load per iteration is a chain of n memory latencies
+    {
+        double acc0 = 0.0, acc1 = 0.0;
+        const int ir = tid < n ? tid : n - 1;
+        for (int j0 = tid & ~63; j0 < n; j0 += 16) {
+            double u[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = j0 + q < n ? j0 + q : n - 1;
+                u[q] = U[(size_t)ir + (size_t)j * ld];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                acc0 = fma(u[q], (j0 + q < n) ? s_z[j0 + q] : 0.0, acc0);
+                acc1 = fma(u[q + 1], (j0 + q + 1 < n) ? s_z[j0 + q + 1] : 0.0, acc1);
+            }
+        }
+        s_av[tid] = acc0 + acc1;
+    }
+    // scaled coordinates for the contraction: in the packed-factor buffer (free now; the staging buffer is the product's)
+    double *xg = s_F;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d)
+        if (d < se.D)
+            for (int i = tid; i < n; i += 256) xg[i + d * n] = __dmul_rn(X[(size_t)i + (size_t)d * ldx], se.inv_ell[d]);
+    __syncthreads();
+    GPMI_STAMP(tg3)
+    GPMI_STAMP_ADD(5, tg3 - tg2)
+    // K^-1 = U U^T tile by tile (lower tiles; only the columns >= the tile row's first), contracted where it is produced:
+    // every element (m, n <= m) of a tile goes from its accumulator register into the sums -- K^-1 is never stored
+    double acc[SMALL_GRAD_NS];
+#pragma unroll
+    for (int q = 0; q < SMALL_GRAD_NS; ++q) acc[q] = 0.0;
+    const double a2 = se.a2;
+    auto kinv_tiles = [&](auto dt) {
+        constexpr int DT = decltype(dt)::value;   // compile-time dimension count (0: se.D at run time, <= GPMI_MAXD)
+        const int Dn = DT ? DT : se.D;
+        constexpr int DH = DT ? DT : 1;        // coordinates kept in registers per row / column (run-time D: re-read from LDS)
+        double xm[4][DH], am[4], xn[DH], an = 0.0;
+        int mm[4], ncur = 0;
+        bool okn = false;
+        auto contract = make_epi3(
+            [&](int tm, int m, bool ok) {
+                mm[tm] = ok ? m : -1;           // a row outside the matrix lies above every column: weight 0
+                const int mc = ok ? m : 0;
+                am[tm] = s_av[mc];
+                if constexpr (DT != 0) {
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) xm[tm][d] = xg[mc + d * n];
+                }
+            },
+            [&](int nn, bool ok) {
+                ncur = ok ? nn : 0;
+                okn = ok;
+                an = s_av[ncur];
+                if constexpr (DT != 0) {
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) xn[d] = xg[ncur + d * n];
+                }
+            },
+            [&](double kinv, int tm) {
+                double e = 0.0, r2[GPMI_MAXD];
+                const int mc = mm[tm] < 0 ? 0 : mm[tm];
+#pragma unroll
+                for (int d = 0; d < (DT ? DT : GPMI_MAXD); ++d) {
+                    double r;
+                    if constexpr (DT != 0) r = xm[tm][d] - xn[d];
+                    else r = d < Dn ? xg[mc + d * n] - xg[ncur + d * n] : 0.0;
+                    r2[d] = r * r;
+                    e += r2[d];
+                }
+                const double kse = a2 * exp_nonpos(-0.5 * e, ec);
+                const double g = 0.5 * (am[tm] * an - kinv);
+                const bool lower = okn && ncur <= mm[tm];
+                const double c = lower ? ((ncur == mm[tm]) ? 1.0 : 2.0) * g * kse : 0.0;
+                acc[0] += c;
+#pragma unroll
+                for (int d = 0; d < (DT ? DT : GPMI_MAXD); ++d) acc[1 + d] += c * r2[d];
+                acc[1 + GPMI_MAXD] += (lower && ncur == mm[tm]) ? g : 0.0;
+            });
+        for (int ti = 0; ti * GT < n; ++ti)
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int k0 = ti * GT;
+                gemm_tile<3>(smem, U + (size_t)k0 * ld, ld, U + (size_t)k0 * ld, ld, W, ld, n, n, n - k0, ti, tj, 0, (int)threadIdx.x,
+                             contract);
+                __syncthreads();
+            }
+    };
+    switch (se.D) {
+    case 1: kinv_tiles(ic<1>{}); break;
+    case 2: kinv_tiles(ic<2>{}); break;
+    case 3: kinv_tiles(ic<3>{}); break;
+    default: kinv_tiles(ic<0>{}); break;
+    }
+    GPMI_STAMP(tg4)
+    GPMI_STAMP_ADD(6, tg4 - tg3)
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d)   // the sums are over UNSCALED squared differences (layout of k_grad_partial)
+        acc[1 + d] = (d < se.D) ? acc[1 + d] / (se.inv_ell[d] * se.inv_ell[d]) : 0.0;
+    __syncthreads();
+    const int info = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // fixed-shape reduction (deterministic): butterfly inside every wave, the four wave sums added in wave order
+#pragma unroll
+    for (int q = 0; q < SMALL_GRAD_NS; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((tid & 63) == 0) s_a[(tid >> 6) * SMALL_GRAD_NS + q] = v;
+    }
+    __syncthreads();
+    if (tid < SMALL_GRAD_NS) {
+        const double v = ((s_a[tid] + s_a[SMALL_GRAD_NS + tid]) + s_a[2 * SMALL_GRAD_NS + tid]) + s_a[3 * SMALL_GRAD_NS + tid];
+        res[3 + tid] = info ? __builtin_nan("") : v;
+    }
+    GPMI_STAMP(tg5)
+    GPMI_STAMP_ADD(7, tg5 - tg4)
+    if (tid == 0) {
+        if (info_out) *info_out = info;
+        if (info) {
+            res[0] = res[1] = res[2] = __builtin_nan("");
+        } else {
+            res[1] = sum_log;
+            res[2] = zz;
+            res[0] = -0.5 * zz - sum_log - 0.5 * (double)n * 1.8378770664093454835606594728112;  // log(2 pi)
+        }
+    }
+}
+
 constexpr int SMALL_PTS = 128;  // grid points per launch: their hyper-parameters travel as kernel arguments
 struct SmallBatch {
     double a2[SMALL_PTS], inv_rho[SMALL_PTS], diag[SMALL_PTS];
@@ -2039,6 +2306,52 @@ __global__ __launch_bounds__(256, 2) void k_logml_small_batch_dev(const double *
     for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = pg[2 + d];
     logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, pg[1], Wall + (size_t)g * wstride, ld, out3 + 3 * (size_t)g,
                      info_out + g, info_w + g, ec);
+}
+
+// value + gradient sums: one evaluation (host-mapped X, y staged as in k_logml_small) ...
+constexpr int SMALL_GRAD_LDS_DOUBLES = SMALL_LDS_DOUBLES + 512;   // s_aux: two reduction arrays + z + a
+__global__ __launch_bounds__(256, 2) void k_logml_grad_small(const double *__restrict__ X, int n, int ldx, const double *__restrict__ y,
+                                                          SeParams p, double diag_add, double *__restrict__ W, size_t ld,
+                                                          double *__restrict__ U, double *__restrict__ res, int *info_out, int *info_w,
+                                                          ExpC ec, double *__restrict__ stage)
+{
+    GPMI_SMALL_LDS
+    if (stage) {
+        const int nx = n * p.D;
+        for (int e = threadIdx.x; e < nx + n; e += 256) {
+            const int d = e / n, i = e - d * n;
+            stage[e] = (e < nx) ? X[(size_t)i + (size_t)d * ldx] : y[e - nx];
+        }
+        __syncthreads();
+        X = stage;
+        y = stage + nx;
+        ldx = n;
+    }
+    SmallSe se;
+    se.a2 = p.a2;
+    se.D = p.D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = p.inv_ell[d];
+    logml_grad_small_body(smem, s_F, s_aux, X, n, ldx, y, se, diag_add, W, ld, U, res, info_out, info_w, ec);
+}
+
+// ... and G isotropic points (the chains of a sampler: rstan's default is four), one workgroup each; slice g of Wall holds
+// W and, ustride doubles behind it, U
+__global__ __launch_bounds__(256, 2) void k_logml_grad_small_batch(const double *__restrict__ X, int n, int ldx, int D,
+                                                                const double *__restrict__ y, SmallBatch b,
+                                                                double *__restrict__ Wall, size_t wstride, size_t ustride, size_t ld,
+                                                                double *__restrict__ res, int *info_out, int *info_w, ExpC ec)
+{
+    GPMI_SMALL_LDS
+    const int g = blockIdx.x;
+    SmallSe se;
+    se.a2 = b.a2[g];
+    se.D = D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = b.inv_rho[g];
+    double *W = Wall + (size_t)g * wstride;
+    logml_grad_small_body(smem, s_F, s_aux, X, n, ldx, y, se, b.diag[g], W, ld, W + ustride, res + (size_t)g * SMALL_GRAD_RES,
+                          info_out + g, info_w + g, ec);
 }
 
 // stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
@@ -2362,6 +2675,9 @@ static void small_lds_attr()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_ard), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_dev), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const int gbytes = SMALL_GRAD_LDS_DOUBLES * (int)sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done[dev] = true;
 }
@@ -2385,6 +2701,9 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->small_n = 256;
     t->small_n1 = 128;
     t->small_m = 160;
+    t->small_ng1 = 128;   // tools/grad_small_bench.py: one workgroup 57 / 82 / 109 / 207 / 303 / 337 us at n = 21 / 64 / 128 / 160 / 199 / 256,
+                          // the launch chain 151 / 162 / 180 / ~225 / 274 / 272; four chains at once 93 .. 363 us against 377 .. 525
+    t->small_ng = 256;
     t->small_n2 = 1024;
     t->small_g2 = 40;
 }
@@ -2986,6 +3305,34 @@ void launch_logml_small_batch_dev(hipStream_t s, const double *dX, int n, int ld
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_small_batch_dev, dim3(G), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, d_par, Wall,
                        stride, ld, d_out3, d_info_out, d_info_work, h_exp);
+}
+
+// value + gradient sums by one workgroup per point: W holds, per point, two slices of small_ws_layout (W, then U)
+void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
+                             double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage)
+{
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_logml_grad_small, dim3(1), 256, SMALL_GRAD_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, dy, p, diag_add, W, ld,
+                       W + stride, d_res, d_info_out, d_info_work, h_exp, stage);
+}
+
+void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                                   const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_res,
+                                   int *d_info_out, int *d_info_work)
+{
+    SmallBatch b;
+    for (int g = 0; g < G; ++g) {
+        b.a2[g] = alpha[g] * alpha[g];
+        b.inv_rho[g] = 1.0 / rho[g];
+        b.diag[g] = sigma[g] * sigma[g] + jitter;
+    }
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_logml_grad_small_batch, dim3(G), 256, SMALL_GRAD_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall,
+                       2 * stride, stride, ld, d_res, d_info_out, d_info_work, h_exp);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

@@ -406,6 +406,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         c->tune.syrk_order = value;
         return 0;
     }
+    if (!strcmp(name, "small_ng1") || !strcmp(name, "small_ng")) {  // one-workgroup value + gradient: one evaluation / several
+        if (value < 0 || value > 256) return gpmi_fail(GPMI_EARG, "%s must be 0 .. 256", name);
+        (name[8] == '1' ? c->tune.small_ng1 : c->tune.small_ng) = value;
+        return 0;
+    }
     if (!strcmp(name, "small_n2")) {  // ... up to this n for grids of at least small_g2 (n / 1024)^2 + 2 points (0: off)
         if (value < 0 || value > GPMI_SMALL_NMAX) return gpmi_fail(GPMI_EARG, "small_n2 must be 0 .. %d", GPMI_SMALL_NMAX);
         c->tune.small_n2 = value;
@@ -1840,6 +1845,40 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
     SeParams p;
     int rc;
     if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
+    if (c->tune.small_ng1 > 0 && n <= c->tune.small_ng1 && D <= GPMI_MAXD) {
+        // the sizes the reference's fits run at: ONE launch of one workgroup; X, y go in and the 13 results come back
+        // through a pinned, device-mapped buffer (no copy call), as in gpmi_logml
+        const size_t need = (16 + (size_t)n * (D + 1)) * sizeof(double);
+        if (need > c->h_pin_bytes) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
+            c->h_pin = c->h_pin_dev = nullptr;
+            c->h_pin_bytes = 0;
+            const size_t want = need > 65536 ? need : 65536;
+            if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
+                return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
+            HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
+            c->h_pin_bytes = want;
+        }
+        double *hX = c->h_pin + 16, *hy = hX + (size_t)n * D, *stage;
+        for (int d = 0; d < D; ++d) memcpy(hX + (size_t)d * n, X + (size_t)d * ldx, (size_t)n * sizeof(double));
+        memcpy(hy, y, (size_t)n * sizeof(double));
+        if ((rc = scratch_buf(c, (size_t)n * (D + 1) * sizeof(double), &stage))) return rc;
+        if ((rc = reserve_ws_small(c, n, 2))) return rc;
+        double *pd = c->h_pin_dev;
+        launch_logml_grad_small(c->stream, pd + 16, n, n, pd + 16 + (size_t)n * D, p, sigma * sigma + jitter, c->W, pd,
+                                (int *)(pd + GPMI_SMALL_GRAD_RES), c->d_info, stage);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const int info = *(const int *)(c->h_pin + GPMI_SMALL_GRAD_RES);
+        for (int k = 0; k < 3; ++k) out3[k] = c->h_pin[k];
+        if (info) {
+            for (int k = 0; k < 2 + n_ell; ++k) grad[k] = NAN;
+            return info;
+        }
+        logml_grad_finish(c->h_pin + 3, D, alpha, ell, n_ell, sigma, grad);
+        return 0;
+    }
     double *dX, *dy, *dres;
     if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
     if ((rc = logml_grad_reserve(c, n, D))) return rc;
@@ -1877,6 +1916,36 @@ extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx
     std::vector<SeParams> ps(G);
     for (int g = 0; g < G; ++g)
         if ((rc = fill_params(&ps[g], D, alpha[g], &rho[g], 1))) return rc;
+    if (D <= GPMI_MAXD && n <= (G >= 2 ? c->tune.small_ng : c->tune.small_ng1)) {
+        // one workgroup per point, up to GPMI_SMALL_PTS points per launch (parameters as kernel arguments)
+        double *dX, *dy, *dres;
+        if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
+        const int per = G < GPMI_SMALL_PTS ? G : GPMI_SMALL_PTS;
+        if ((rc = reserve_ws_small(c, n, 2 * per))) return rc;
+        if ((rc = reserve_small_par(c, G))) return rc;   // work ints (one per point of a launch)
+        if ((rc = scratch_buf(c, ((size_t)G * (GPMI_SMALL_GRAD_RES + 1) + 8) * sizeof(double), &dres))) return rc;
+        int *dinfo = (int *)(dres + (size_t)G * GPMI_SMALL_GRAD_RES);
+        for (int g0 = 0; g0 < G; g0 += per) {
+            const int gc = (G - g0 < per) ? G - g0 : per;
+            launch_logml_grad_small_batch(c->stream, dX, n, n, D, dy, alpha + g0, rho + g0, sigma + g0, gc, jitter, c->W,
+                                          dres + (size_t)g0 * GPMI_SMALL_GRAD_RES, dinfo + g0, c->d_sinfo);
+        }
+        std::vector<double> hr((size_t)G * GPMI_SMALL_GRAD_RES);
+        HIPCHK(hipMemcpyAsync(hr.data(), dres, hr.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(info, dinfo, (size_t)G * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipGetLastError());
+        for (int g = 0; g < G; ++g) {
+            const double *r = hr.data() + (size_t)g * GPMI_SMALL_GRAD_RES;
+            for (int k = 0; k < 3; ++k) out3[3 * g + k] = r[k];
+            if (info[g]) {
+                for (int k = 0; k < 3; ++k) grad[3 * g + k] = NAN;
+            } else {
+                logml_grad_finish(r + 3, D, alpha[g], &rho[g], 1, sigma[g], grad + 3 * g);
+            }
+        }
+        return 0;
+    }
     int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
     if (lanes > 8) lanes = 8;
     if (lanes > G) lanes = G;

@@ -36,6 +36,7 @@ struct gpmi_tuning {
     int small_n;          // grids of marginal likelihoods at n <= small_n (and D <= GPMI_MAXD): one workgroup per point, one launch (0: off)
     int small_n1;         // ... a single evaluation (or a grid of fewer than 6 points) up to this n: beyond it the multi-CU launch chain is faster
     int small_m;          // partial factorisation of <= small_m rows: one workgroup, one launch (0: off)
+    int small_ng1, small_ng; // value + gradient by one workgroup: one evaluation up to n <= small_ng1, several (a sampler's chains) up to small_ng (<= 256; 0: off)
     int small_n2, small_g2;  // grids of >= small_g2 (n / 1024)^2 + 2 points: one workgroup per point up to n <= small_n2 (every CU a problem of its own)
 };
 void gpmi_tuning_defaults(gpmi_tuning *t);
@@ -168,6 +169,14 @@ void launch_logml_small_batch_ard(hipStream_t s, const double *dX, int n, int ld
 void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                               const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_out3,
                               int *d_info_out, int *d_info_work);
+// value + gradient sums (GPMI_SMALL_GRAD_RES doubles per point: logml, sum log L_ii, z'z, then the GRAD_NS = 10 contraction
+// sums) by one workgroup per point, n <= 256; the workspace holds TWO slices of small_ws_layout per point (W, then U = L^-T)
+#define GPMI_SMALL_GRAD_RES (3 + 2 + GPMI_MAXD)
+void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
+                             double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage);
+void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
+                                   const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_res,
+                                   int *d_info_out, int *d_info_work);
 // any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
 #define GPMI_SMALL_PAR (2 + GPMI_MAXD)
 #define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS

@@ -18,7 +18,7 @@ def test_grad_vs_oracle(ctx, orc, n, D):
     want_out, want_g, info = orc.logml_grad(X, y, a, r, s)
     assert info == 0
     assert abs(out[0] - want_out[0]) <= 1e-9 * abs(want_out[0])
-    assert out[0] == ctx.logml(X, y, a, [r], s)[0]  # same factorisation as the plain entry point
+    assert out[0] == ctx.logml(X, y, a, [r], s)[0]  # same factorisation as the plain entry point (one workgroup up to n = 128, the launch chain beyond)
     np.testing.assert_allclose(g, want_g, rtol=1e-8, atol=1e-8 * np.abs(want_g).max())
 
 
@@ -113,3 +113,77 @@ def test_grad_grid_on_lanes_equals_single_calls(ctx, orc):
     assert lp[3] == -math.inf and np.all(np.isnan(grad[3]))
     lp1, grad1 = sm.fit_hyperparameters_log_prob_grad(X, y, r[2], a[2], s[2], ctx=ctx)
     assert lp[2] == lp1 and np.array_equal(grad[2], grad1)
+
+
+@pytest.mark.parametrize("D", [1, 3, 8])
+def test_small_value_and_gradient_by_one_workgroup(ctx, orc, D):
+    """n <= 256 (the sizes the reference's Stan fits run at: R/tests.R:5 N = 21, pendulum_fit.R 79 .. 199): value and
+    gradient in ONE launch of one workgroup (k_logml_grad_small) against the oracle, against the launch chain
+    (small_ng1 = 0) and, for ARD, against the oracle on inputs scaled per dimension."""
+    worst = worst_chain = 0.0
+    ctx.set_option("small_ng1", 256)   # default 128: a SINGLE evaluation beyond one panel is faster through the launch chain
+    for n in (1, 2, 5, 16, 17, 21, 64, 79, 127, 128, 129, 160, 199, 255, 256):
+        rng = np.random.default_rng(10 * n + D)
+        X = rng.random((n, D)) * (1.0 + n / 60.0); y = np.sin(3 * X.sum(axis=1)) + 0.1 * rng.standard_normal(n)
+        a, r, s = 1.2, 0.4 * math.sqrt(D), 0.15
+        out, g = ctx.logml_grad(X, y, a, [r], s)
+        want_out, want_g, info = orc.logml_grad(X, y, a, r, s)
+        assert info == 0 and abs(out[0] - want_out[0]) <= 1e-9 * abs(want_out[0]), (n, out, want_out)
+        np.testing.assert_allclose(g, want_g, rtol=1e-8, atol=1e-8 * np.abs(want_g).max(), err_msg="n=%d" % n)
+        worst = max(worst, np.max(np.abs(g - want_g)) / np.abs(want_g).max())
+        if n in (21, 128, 199, 256):
+            ctx.set_option("small_ng1", 0)
+            try:
+                out_c, g_c = ctx.logml_grad(X, y, a, [r], s)
+            finally:
+                ctx.set_option("small_ng1", 256)
+            assert abs(out[0] - out_c[0]) <= 1e-12 * abs(out_c[0])
+            np.testing.assert_allclose(g, g_c, rtol=1e-9, atol=1e-9 * np.abs(g_c).max())
+            worst_chain = max(worst_chain, np.max(np.abs(g - g_c)) / np.abs(g_c).max())
+    print("one-workgroup gradient, D=%d: worst vs oracle %.1e, vs the launch chain %.1e" % (D, worst, worst_chain))
+    ctx.set_option("small_ng1", 128)
+    if D > 1:   # ARD: d/d ell_d against central differences of the value
+        n = 150
+        rng = np.random.default_rng(D)
+        X = rng.random((n, D)); y = np.cos(2 * X[:, 0]) + 0.05 * rng.standard_normal(n)
+        ell = 0.5 + rng.random(D)
+        _, g = ctx.logml_grad(X, y, 0.9, ell, 0.2)
+        h = 1e-5
+        f = lambda a_, e_, s_: ctx.logml(X, y, a_, e_, s_)[0]
+        fd = [(f(0.9 + h, ell, 0.2) - f(0.9 - h, ell, 0.2)) / (2 * h)]
+        for d in range(D):
+            e = np.zeros(D); e[d] = h
+            fd.append((f(0.9, ell + e, 0.2) - f(0.9, ell - e, 0.2)) / (2 * h))
+        fd.append((f(0.9, ell, 0.2 + h) - f(0.9, ell, 0.2 - h)) / (2 * h))
+        np.testing.assert_allclose(g, fd, rtol=5e-6, atol=2e-6)
+
+
+def test_small_gradient_chains_in_one_launch(ctx, orc):
+    """gpmi_logml_grad_grid at n <= 256: the chains are workgroups of ONE launch (k_logml_grad_small_batch); each equals
+    the single call bit for bit, a rejected (non-PD) proposal gives NaN + info and does not disturb the others; more
+    points than one launch carries (128) are cut into launches."""
+    t = np.linspace(-2, 2, 21); y = np.exp(t)          # the R/tests.R:5 grid
+    a = np.array([1.0, 1.1, 0.9, 1.0]); r = np.array([0.9, 1.0, 50.0, 0.8]); s = np.array([0.07, 0.1, 1e-9, 0.2])
+    out, g, info = ctx.logml_grad_grid(t, y, a, r, s)
+    assert info[2] > 0 and np.all(np.isnan(g[2])) and np.all(np.isnan(out[2])) and np.all(np.delete(info, 2) == 0)
+    for k in (0, 1, 3):
+        o1, g1 = ctx.logml_grad(t, y, a[k], [r[k]], s[k])
+        assert np.array_equal(out[k], o1) and np.array_equal(g[k], g1)
+        wo, wg, _ = orc.logml_grad(t.reshape(-1, 1), y, a[k], r[k], s[k])
+        np.testing.assert_allclose(g[k], wg, rtol=1e-8, atol=1e-8 * np.abs(wg).max())
+    X, yy = orc.synth(199, 1)
+    G = 150
+    rng = np.random.default_rng(4)
+    a = 0.8 + 0.4 * rng.random(G); r = 0.2 + 0.3 * rng.random(G); s = 0.05 + 0.2 * rng.random(G)
+    out, g, info = ctx.logml_grad_grid(X, yy, a, r, s)
+    assert np.all(info == 0)
+    ctx.set_option("small_ng1", 256)   # the single call through the same kernel: bit for bit
+    try:
+        for k in (0, 127, 128, 149):
+            o1, g1 = ctx.logml_grad(X, yy, a[k], [r[k]], s[k])
+            assert np.array_equal(out[k], o1) and np.array_equal(g[k], g1)
+    finally:
+        ctx.set_option("small_ng1", 128)
+    o1, g1 = ctx.logml_grad(X, yy, a[5], [r[5]], s[5])   # default: the launch chain at n = 199 -- same numbers to rounding
+    assert abs(out[5, 0] - o1[0]) <= 1e-12 * abs(o1[0])
+    np.testing.assert_allclose(g[5], g1, rtol=1e-9, atol=1e-9 * np.abs(g1).max())
