@@ -2354,6 +2354,80 @@ __global__ __launch_bounds__(256, 2) void k_logml_grad_small_batch(const double 
                           info_out + g, info_w + g, ec);
 }
 
+// One posterior draw of the derivative process (sample_derivs, pendulum_fit.R:227-255) per workgroup: the loop
+// mclapply(s_list[1:100], sample_derivs_both_states, mc.cores = 2) (:261-268) is B independent draws, each with its own
+// (l, a, sy) and noisy series, at n = m = 199 -- a chain of ~25 latency-bound launches per draw on the blocked path.  Here
+// draw b builds [[a^2 QQ + sy^2 I, .], [a^2 RQ, a^2 RR]] with the row [y^T, 0] (the arithmetic of k_deriv_cov: deriv_val),
+// factors the first n columns (Schur complement = cov - jitter I in the trailing block, -mu^T in the last row), adds the
+// jitter, factors the m x m block in place and forms mu + chol(cov) z -- the composition of sample_derivs_core.
+// par[3 g ..] = (l, a, sy) of draw g, in device memory (any number of draws per launch).
+// status: 0, k (K + sy^2 I not PD at order k), n + k (cov).
+__global__ __launch_bounds__(256, 2) void k_sample_derivs_small_batch(const double *__restrict__ t, int n, const double *__restrict__ ts,
+                                                                   int m, const double *__restrict__ Y, const double *__restrict__ par,
+                                                                   double jitter, const double *__restrict__ Z, double *__restrict__ Wall,
+                                                                   size_t wstride, size_t ld, double *__restrict__ draws,
+                                                                   double *__restrict__ mus, int *__restrict__ status,
+                                                                   int *__restrict__ info_w)
+{
+    GPMI_SMALL_LDS
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int nt = n + m;
+    double *W = Wall + (size_t)g * wstride;
+    const double a2 = par[3 * g + 1] * par[3 * g + 1], l2 = par[3 * g] * par[3 * g], s2 = par[3 * g + 2] * par[3 * g + 2];
+    const double *y = Y + (size_t)g * n, *z = Z + (size_t)g * m;
+    int *iw = info_w + 2 * g;
+    if (tid < 2) iw[tid] = 0;
+    // lower triangle of the joint matrix, thread = row, and the augmented row
+    for (int i = tid; i < nt; i += 256) {
+        const bool star = i >= n;
+        const double xi = star ? ts[i - n] : t[i];
+        const int jn = i < n ? i + 1 : n;
+        for (int j = 0; j < jn; ++j) {
+            double v = a2 * deriv_val(star ? GPMI_RQ : GPMI_QQ, xi, t[j], l2);
+            if (i == j) v += s2;
+            W[(size_t)i + (size_t)j * ld] = v;
+        }
+        for (int j = n; j <= i; ++j) W[(size_t)i + (size_t)j * ld] = a2 * deriv_val(GPMI_RR, xi, ts[j - n], l2);
+    }
+    for (int j = tid; j < nt; j += 256) W[(size_t)nt + (size_t)j * ld] = j < n ? y[j] : 0.0;
+    __syncthreads();
+    small_potrf_partial(smem, s_F, s_aux, W, ld, nt + 1, nt, n, iw, false);
+    __syncthreads();
+    double *S = W + (size_t)n + (size_t)n * ld;
+    for (int j = tid; j < m; j += 256) {
+        S[(size_t)j * (ld + 1)] += jitter;
+        const double mu = -W[(size_t)nt + (size_t)(n + j) * ld];
+        mus[(size_t)g * m + j] = mu;
+    }
+    __syncthreads();
+    small_potrf_partial(smem, s_F, s_aux, S, ld, m, m, m, iw + 1, false);
+    __syncthreads();
+    // draw = mu + L z: row i, columns 0 .. i in order (the order of k_trmv_lower_part within a chunk), sixteen loads in flight
+    for (int i0 = 0; i0 < m; i0 += 256) {
+        const int i = i0 + tid, ic = i < m ? i : m - 1;
+        double acc = 0.0;
+        const int jend = (i0 + 255 < m ? i0 + 255 : m - 1);   // workgroup-uniform bound; columns > i contribute exact zeros
+        for (int j0 = 0; j0 <= jend; j0 += 16) {
+            double u[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = j0 + q <= ic ? j0 + q : ic;
+                u[q] = S[(size_t)ic + (size_t)j * ld];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (j0 + q <= ic) acc = fma(u[q], z[j0 + q], acc);
+        }
+        if (i < m) draws[(size_t)g * m + i] = acc + mus[(size_t)g * m + i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int i1 = __hip_atomic_load(iw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int i2 = __hip_atomic_load(iw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        status[g] = i1 ? i1 : (i2 ? n + i2 : 0);
+    }
+}
+
 // stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
 // have to be fenced against an earlier asynchronous call)
 constexpr int PUT_MAX = 480;
@@ -2675,6 +2749,7 @@ static void small_lds_attr()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_ard), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_dev), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sample_derivs_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     const int gbytes = SMALL_GRAD_LDS_DOUBLES * (int)sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
@@ -2704,6 +2779,8 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->small_ng1 = 128;   // tools/grad_small_bench.py: one workgroup 57 / 82 / 109 / 207 / 303 / 337 us at n = 21 / 64 / 128 / 160 / 199 / 256,
                           // the launch chain 151 / 162 / 180 / ~225 / 274 / 272; four chains at once 93 .. 363 us against 377 .. 525
     t->small_ng = 256;
+    t->small_sd = 640;
+    t->small_sdb = 5;     // tools/sample_derivs_bench.py: one workgroup 0.21 / 0.56 / 0.73 ms at n = m = 79 / 199 / 256, the lanes 95 / 136 / 129 us per draw
     t->small_n2 = 1024;
     t->small_g2 = 40;
 }
@@ -3333,6 +3410,26 @@ void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int l
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_grad_small_batch, dim3(G), 256, SMALL_GRAD_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall,
                        2 * stride, stride, ld, d_res, d_info_out, d_info_work, h_exp);
+}
+
+// B draws by one workgroup each; Wall: B slices of small_ws_layout(n + m); dY: n x B, dZ, draws, mus: m x B (packed); d_par: 3 B
+// doubles, d_info_work: 2 B ints
+void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, const double *dts, int m, const double *dY,
+                                      const double *params /* host: (l, a, sy) per draw */, int B, double jitter, const double *dZ,
+                                      double *d_par, double *Wall, double *d_draws, double *d_mus, int *d_status, int *d_info_work)
+{
+    static_assert(PUT_MAX % 3 == 0, "whole draws per upload");
+    PutArgs a;
+    for (int g0 = 0; g0 < B; g0 += PUT_MAX / 3) {
+        const int gc = (B - g0 < PUT_MAX / 3) ? B - g0 : PUT_MAX / 3;
+        for (int q = 0; q < 3 * gc; ++q) a.v[q] = params[3 * (size_t)g0 + q];
+        hipLaunchKernelGGL(k_put_doubles, dim3(1), 256, 0, s, a, d_par + 3 * (size_t)g0, 3 * gc);
+    }
+    size_t ld, stride;
+    small_ws_layout(n + m, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_sample_derivs_small_batch, dim3(B), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dt, n, dts, m, dY, d_par, jitter, dZ,
+                       Wall, stride, ld, d_draws, d_mus, d_status, d_info_work);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

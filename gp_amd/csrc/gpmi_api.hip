@@ -411,6 +411,16 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         (name[8] == '1' ? c->tune.small_ng1 : c->tune.small_ng) = value;
         return 0;
     }
+    if (!strcmp(name, "small_sd")) {  // sample_derivs[_batch]: one workgroup per draw up to this many rows n + m + 1 (0: off)
+        if (value < 0 || value > 1024) return gpmi_fail(GPMI_EARG, "small_sd must be 0 .. 1024");
+        c->tune.small_sd = value;
+        return 0;
+    }
+    if (!strcmp(name, "small_sdb")) {  // ... for at least small_sdb ((n + m + 1) / 400)^2 draws
+        if (value < 0) return gpmi_fail(GPMI_EARG, "small_sdb must be >= 0");
+        c->tune.small_sdb = value;
+        return 0;
+    }
     if (!strcmp(name, "small_n2")) {  // ... up to this n for grids of at least small_g2 (n / 1024)^2 + 2 points (0: off)
         if (value < 0 || value > GPMI_SMALL_NMAX) return gpmi_fail(GPMI_EARG, "small_n2 must be 0 .. %d", GPMI_SMALL_NMAX);
         c->tune.small_n2 = value;
@@ -2095,6 +2105,34 @@ static int sample_derivs_core(gpmi_ctx *c, const double *dt, int n, const double
     return 0;
 }
 
+// one workgroup per draw (k_sample_derivs_small_batch) instead of a launch chain per draw on the lanes: a workgroup needs
+// ~(n + m)^3 time but every draw has a CU of its own (tools/sample_derivs_bench.py)
+static bool small_sample_derivs(const gpmi_ctx *c, int n, int m, int B)
+{
+    const int M = n + m + 1;
+    if (c->tune.small_sd <= 0 || M > c->tune.small_sd) return false;
+    const double r = (double)M / 400.0;
+    return (double)B >= (double)c->tune.small_sdb * r * r;
+}
+
+// device pointers, packed columns; enqueues on c->stream
+static int sample_derivs_small(gpmi_ctx *c, const double *dt, int n, const double *dts, int m, const double *dY, const double *params,
+                               int B, double jitter, const double *dZ, double *dD, double *dM, int *dst)
+{
+    int rc;
+    const int per = B < GPMI_SMALL_DEV_PTS ? B : GPMI_SMALL_DEV_PTS;
+    if ((rc = reserve_ws_small(c, n + m, per))) return rc;
+    if ((rc = reserve_small_par(c, 2 * per))) return rc;
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int bc = (B - b0 < per) ? B - b0 : per;
+        launch_sample_derivs_small_batch(c->stream, dt, n, dts, m, dY + (size_t)b0 * n, params + 3 * (size_t)b0, bc, jitter,
+                                         dZ + (size_t)b0 * m, c->d_spar, c->W, dD + (size_t)b0 * m, dM + (size_t)b0 * m, dst + b0,
+                                         c->d_sinfo);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gpmi_sample_derivs(gpmi_ctx *c, const double *t, int n, const double *ts, int m, const double *y,
                                   double l, double a, double sy, double jitter, const double *z, double *draw, double *mu)
 {
@@ -2111,7 +2149,10 @@ extern "C" int gpmi_sample_derivs(gpmi_ctx *c, const double *t, int n, const dou
     HIPCHK(hipMemcpyAsync(dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dts, ts, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(dz, z, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
-    if ((rc = sample_derivs_core(c, dt, n, dts, m, dy, a, l, sy * sy, jitter, dz, ddraw, dmu, dst))) return rc;
+    if (small_sample_derivs(c, n, m, 1)) {   // small enough that one workgroup beats the launch chain even for ONE draw
+        const double par[3] = {l, a, sy};
+        if ((rc = sample_derivs_small(c, dt, n, dts, m, dy, par, 1, jitter, dz, ddraw, dmu, dst))) return rc;
+    } else if ((rc = sample_derivs_core(c, dt, n, dts, m, dy, a, l, sy * sy, jitter, dz, ddraw, dmu, dst))) return rc;
     int st = 0;
     HIPCHK(hipMemcpyAsync(draw, ddraw, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
     if (mu) HIPCHK(hipMemcpyAsync(mu, dmu, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2135,12 +2176,15 @@ extern "C" int gpmi_sample_derivs_batch(gpmi_ctx *c, const double *t, int n, con
     for (int b = 0; b < B; ++b)
         if (!(params[3 * b] > 0.0)) return gpmi_fail(GPMI_EARG, "length-scale must be positive");
     int rc;
+    const bool small = small_sample_derivs(c, n, m, B);
     int lanes = c->grid_lanes > 0 ? c->grid_lanes : 4;
     if (lanes > 8) lanes = 8;
     if (lanes > B) lanes = B;
-    if ((rc = lanes_prepare(c, lanes))) return rc;
-    for (int l = 0; l < lanes; ++l)
-        if ((rc = sample_derivs_reserve(l ? c->lane[l - 1] : c, n, m))) return rc;
+    if (!small) {
+        if ((rc = lanes_prepare(c, lanes))) return rc;
+        for (int l = 0; l < lanes; ++l)
+            if ((rc = sample_derivs_reserve(l ? c->lane[l - 1] : c, n, m))) return rc;
+    }
     double *d;
     const size_t nb = (size_t)n * B, mb = (size_t)m * B;
     if ((rc = stage_buf(c, 0, ((size_t)n + m + nb + 3 * mb + B + 8) * sizeof(double), &d))) return rc;
@@ -2151,16 +2195,20 @@ extern "C" int gpmi_sample_derivs_batch(gpmi_ctx *c, const double *t, int n, con
     HIPCHK(hipMemcpyAsync(dts, ts, (size_t)m * sizeof(double), hipMemcpyHostToDevice, caller));
     HIPCHK(hipMemcpy2DAsync(dY, (size_t)n * sizeof(double), Y, (size_t)ldy * sizeof(double), (size_t)n * sizeof(double), B, hipMemcpyHostToDevice, caller));
     HIPCHK(hipMemcpy2DAsync(dZ, (size_t)m * sizeof(double), Z, (size_t)ldz * sizeof(double), (size_t)m * sizeof(double), B, hipMemcpyHostToDevice, caller));
-    const int la_saved = c->lookahead;
-    lanes_fork(c, lanes, caller);
-    for (int b = 0; b < B && !rc; ++b) {
-        gpmi_ctx *lc = (b % lanes == 0) ? c : c->lane[b % lanes - 1];
-        const double l = params[3 * b], a = params[3 * b + 1], sy = params[3 * b + 2];
-        rc = sample_derivs_core(lc, dt, n, dts, m, dY + (size_t)b * n, a, l, sy * sy, jitter, dZ + (size_t)b * m, dD + (size_t)b * m,
-                                dM + (size_t)b * m, dst + b);
+    if (small) {
+        if ((rc = sample_derivs_small(c, dt, n, dts, m, dY, params, B, jitter, dZ, dD, dM, dst))) return rc;
+    } else {
+        const int la_saved = c->lookahead;
+        lanes_fork(c, lanes, caller);
+        for (int b = 0; b < B && !rc; ++b) {
+            gpmi_ctx *lc = (b % lanes == 0) ? c : c->lane[b % lanes - 1];
+            const double l = params[3 * b], a = params[3 * b + 1], sy = params[3 * b + 2];
+            rc = sample_derivs_core(lc, dt, n, dts, m, dY + (size_t)b * n, a, l, sy * sy, jitter, dZ + (size_t)b * m, dD + (size_t)b * m,
+                                    dM + (size_t)b * m, dst + b);
+        }
+        lanes_join(c, lanes, caller, la_saved);
+        if (rc) return rc;
     }
-    lanes_join(c, lanes, caller, la_saved);
-    if (rc) return rc;
     HIPCHK(hipMemcpy2DAsync(draws, (size_t)ldd * sizeof(double), dD, (size_t)m * sizeof(double), (size_t)m * sizeof(double), B, hipMemcpyDeviceToHost, caller));
     if (mus) HIPCHK(hipMemcpy2DAsync(mus, (size_t)ldmu * sizeof(double), dM, (size_t)m * sizeof(double), (size_t)m * sizeof(double), B, hipMemcpyDeviceToHost, caller));
     HIPCHK(hipMemcpyAsync(info, dst, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, caller));

@@ -37,6 +37,7 @@ struct gpmi_tuning {
     int small_n1;         // ... a single evaluation (or a grid of fewer than 6 points) up to this n: beyond it the multi-CU launch chain is faster
     int small_m;          // partial factorisation of <= small_m rows: one workgroup, one launch (0: off)
     int small_ng1, small_ng; // value + gradient by one workgroup: one evaluation up to n <= small_ng1, several (a sampler's chains) up to small_ng (<= 256; 0: off)
+    int small_sd, small_sdb; // sample_derivs_batch: one workgroup per draw when n + m + 1 <= small_sd rows and at least small_sdb (n + m + 1)^2 / 400^2 draws (0: off)
     int small_n2, small_g2;  // grids of >= small_g2 (n / 1024)^2 + 2 points: one workgroup per point up to n <= small_n2 (every CU a problem of its own)
 };
 void gpmi_tuning_defaults(gpmi_tuning *t);
@@ -177,6 +178,11 @@ void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, co
 void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                                    const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_res,
                                    int *d_info_out, int *d_info_work);
+// B posterior draws of the derivative process, one workgroup each (workspace: B slices of small_ws_layout(n + m); d_par: 3 B doubles,
+// d_info_work: 2 B ints)
+void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, const double *dts, int m, const double *dY,
+                                      const double *params, int B, double jitter, const double *dZ, double *d_par, double *Wall,
+                                      double *d_draws, double *d_mus, int *d_status, int *d_info_work);
 // any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
 #define GPMI_SMALL_PAR (2 + GPMI_MAXD)
 #define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS

@@ -118,27 +118,6 @@ __global__ __launch_bounds__(256) void k_se_cov_big(const double *__restrict__ X
     }
 }
 
-// derivative_kernels.R:39-73 with unit amplitude; r = tj - tk, e = exp(-r^2/(2 l^2)).
-__device__ __forceinline__ double deriv_val(int kind, double tj, double tk, double l2)
-{
-    if (kind == GPMI_RQ || kind == GPMI_TQ || kind == GPMI_TR) {  // :47-49, :59-61, :67-69
-        const double t = tj; tj = tk; tk = t;
-        kind -= 1;
-    }
-    const double r = tj - tk;
-    const double e = exp(-(r * r / (2 * l2)));
-    switch (kind) {
-    case GPMI_QQ: return e;                                                       // :39-41
-    case GPMI_QR: return (e * r) / l2;                                            // :43-45
-    case GPMI_RR: return e / l2 - (e * r * r) / (l2 * l2);                        // :51-53
-    case GPMI_QT: return -(e / l2) + (e * r * r) / (l2 * l2);                     // :55-57
-    case GPMI_RT: return (3 * e * r) / (l2 * l2) - (e * r * r * r) / (l2 * l2 * l2);  // :63-65
-    default:      // GPMI_TT :71-73
-        return (3 * e) / (l2 * l2) - (6 * e * r * r) / (l2 * l2 * l2) +
-               (e * r * r * r * r) / (l2 * l2 * l2 * l2);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_deriv_cov(int kind, const double *__restrict__ x, int n,
                                                    const double *__restrict__ y, int m, double a2,
                                                    double l2, int compat, int lower,

@@ -144,16 +144,20 @@ def test_r_shim_parses_and_matches_the_r_wrappers():
 
 def test_no_valu_write_in_front_of_a_dpp_read_in_the_built_kernels():
     """factor16's DPP chain (hand-written `asm`, its own hazard spacing) as the compiler actually laid it out in every
-    kernel that embeds it: no VALU write of a register within two wait states in front of a DPP read of it (the
-    hardware does not interlock that; a register-allocator copy there gave wrong numbers in round 3).  Compiles
-    chol_kernels.hip to assembly (~1 min) and scans it with tools/dpp_hazard_scan.py."""
+    kernel of the BUILT library that embeds it: no VALU write of a register within two wait states in front of a DPP
+    read of it (the hardware does not interlock that; a register-allocator copy there gave wrong numbers in round 3).
+    Disassembles the code objects of libgpmi.so (llvm-objdump) and scans them with tools/dpp_hazard_scan.py."""
     import importlib.util
     import tempfile
+    from gp_amd import _build
+    lib = _build.build()
     spec = importlib.util.spec_from_file_location("dpp_hazard_scan", os.path.join(ROOT, "tools", "dpp_hazard_scan.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    path = os.path.join(tempfile.mkdtemp(), "chol_kernels.s")
-    mod.compile_asm(path)
-    n, suspects = mod.scan(path, verbose=False)
-    assert n >= 6 * 352, n          # the chain is in the diagonal kernel, both update kernels and the small kernels
+    n = suspects = 0
+    for path in mod.disassemble(lib, tempfile.mkdtemp()):
+        a, b = mod.scan(path, verbose=False)
+        n += a
+        suspects += b
+    assert n >= 10 * 352, n         # the chain is in the diagonal kernel, both update kernels and every one-workgroup kernel
     assert suspects == 0

@@ -233,3 +233,46 @@ def test_mid_size_policy_and_large_point_counts(ctx, orc):
     for g in (0, 33, 69):
         want = orc.logml(X / ell[g], y, 1.0, 1.0, sig[g])
         assert abs(out[g, 0] - want[0]) <= RTOL * abs(want[0])
+
+
+@pytest.mark.parametrize("n,m,B", [(25, 25, 3), (79, 40, 9), (199, 199, 12), (256, 300, 10)])
+def test_sample_derivs_loop_one_workgroup_per_draw(ctx, orc, n, m, B):
+    """The reference's derivative-imputation loop (pendulum_fit.R:261-268: 2 x 100 calls of sample_derivs, N = 199, each with
+    its own (l, a, sy) and noisy series) as ONE launch, one workgroup per draw (k_sample_derivs_small_batch): moments against
+    the reference's formulas with LU solves (pendulum_fit.R:242-251), the draw against numpy's Cholesky of that covariance
+    (tolerance from its conditioning: jitter 1e-6), against the launch chains on the lanes, and a numerically singular
+    draw that does not disturb the others."""
+    rng = np.random.default_rng(n + m)
+    t = np.sort(rng.uniform(0, n / 10.0, n)); tis = np.sort(rng.uniform(0, n / 10.0, m))
+    P = np.column_stack([0.8 + 0.3 * rng.random(B), 1.0 + 0.4 * rng.random(B), 0.05 + 0.1 * rng.random(B)])
+    Y = np.sin(t)[:, None] + 0.1 * rng.standard_normal((n, B)); Z = rng.standard_normal((m, B))
+    jit = 1e-6
+    ctx.set_option("small_sdb", 0)        # one workgroup per draw whatever the batch size
+    try:
+        draws, mus, info = ctx.sample_derivs_batch(t, tis, Y, P, jit, Z)
+        Pbad = P.copy(); Pbad[1, 2] = 0.0; Pbad[1, 0] = 500.0     # sy = 0, huge length-scale: K is numerically singular
+        dbad, _, ibad = ctx.sample_derivs_batch(t, tis, Y, Pbad, 0.0, Z)
+    finally:
+        ctx.set_option("small_sdb", 5)
+    assert np.all(info == 0)
+    assert ibad[1] != 0
+    worst_mu = worst_d = 0.0
+    for b in range(0, B, 3):
+        l, a, sy = P[b]
+        K = orc.deriv_cov("QQ", t, t, a, l) + sy * sy * np.eye(n)
+        Ks = orc.deriv_cov("RQ", tis, t, a, l); Kss = orc.deriv_cov("RR", tis, tis, a, l)
+        mu_ref = Ks @ np.linalg.solve(K, Y[:, b])
+        cov_ref = Kss - Ks @ np.linalg.solve(K, Ks.T) + jit * np.eye(m)
+        d_ref = mu_ref + np.linalg.cholesky(0.5 * (cov_ref + cov_ref.T)) @ Z[:, b]
+        worst_mu = max(worst_mu, np.max(np.abs(mus[:, b] - mu_ref)) / np.max(np.abs(mu_ref)))
+        worst_d = max(worst_d, np.max(np.abs(draws[:, b] - d_ref)) / np.max(np.abs(d_ref)))
+    assert worst_mu <= RTOL and worst_d <= 1e-7, (worst_mu, worst_d)
+    ctx.set_option("small_sd", 0)         # the same batch through the launch chains on the lanes
+    try:
+        dl, ml, il = ctx.sample_derivs_batch(t, tis, Y, P, jit, Z)
+    finally:
+        ctx.set_option("small_sd", 640)
+    assert np.all(il == 0)
+    assert np.max(np.abs(mus - ml)) <= 1e-11 * np.max(np.abs(ml)) and np.max(np.abs(draws - dl)) <= 1e-7 * np.max(np.abs(dl))
+    print("sample_derivs n=%d m=%d B=%d, one workgroup per draw: mu rel %.1e, draw rel %.1e; vs the lanes mu %.1e draw %.1e"
+          % (n, m, B, worst_mu, worst_d, np.max(np.abs(mus - ml)) / np.max(np.abs(ml)), np.max(np.abs(draws - dl)) / np.max(np.abs(dl))))
