@@ -2428,6 +2428,57 @@ __global__ __launch_bounds__(256, 2) void k_sample_derivs_small_batch(const doub
     }
 }
 
+// gpmi_gp_condition (p_Xn / p_dotXn, R/ode_gp.R:1-32; the moments of sample_derivs) at the sizes R/tests.R runs it by ONE
+// workgroup: joint matrix [[K + s2 I, .], [Ks, Kss]] with the row [y^T, 0] (deriv_cov_val: the arithmetic of k_deriv_cov),
+// partial factorisation of the first n columns, then Kn = Schur complement mirrored + jitter I and mn = minus the last row --
+// the launch chain's nine kernels and six copies in one launch.  stage (nullable): t, ts, y are host-mapped and are copied
+// to device memory first; Kn / mn / info_out may be host-mapped as well.
+struct CondArgs {
+    int kindK, kindS, kindSS, compat;
+    double a2, l2, s2, jitter;
+};
+__global__ __launch_bounds__(256, 2) void k_gp_condition_small(const double *__restrict__ t, int n, const double *__restrict__ ts, int m,
+                                                            const double *__restrict__ y, CondArgs q, double *__restrict__ W, size_t ld,
+                                                            double *__restrict__ Kn, size_t ldo, double *__restrict__ mn, int *info_out,
+                                                            int *info_w, double *__restrict__ stage)
+{
+    GPMI_SMALL_LDS
+    const int tid = threadIdx.x, nt = n + m;
+    if (stage) {
+        for (int e = tid; e < 2 * n + m; e += 256) stage[e] = e < n ? t[e] : (e < nt ? ts[e - n] : y[e - nt]);
+        __syncthreads();
+        t = stage;
+        ts = stage + n;
+        y = stage + nt;
+    }
+    if (tid == 0) *info_w = 0;
+    for (int i = tid; i < nt; i += 256) {
+        const bool star = i >= n;
+        const double xi = star ? ts[i - n] : t[i];
+        const int jn = i < n ? i + 1 : n;
+        for (int j = 0; j < jn; ++j) {
+            double v = deriv_cov_val(star ? q.kindS : q.kindK, q.compat, q.a2, xi, t[j], q.l2);
+            if (i == j) v += q.s2;
+            W[(size_t)i + (size_t)j * ld] = v;
+        }
+        for (int j = n; j <= i; ++j) W[(size_t)i + (size_t)j * ld] = deriv_cov_val(q.kindSS, q.compat, q.a2, xi, ts[j - n], q.l2);
+    }
+    for (int j = tid; j < nt; j += 256) W[(size_t)nt + (size_t)j * ld] = j < n ? y[j] : 0.0;
+    __syncthreads();
+    small_potrf_partial(smem, s_F, s_aux, W, ld, nt + 1, nt, n, info_w, false);
+    __syncthreads();
+    const double *S = W + (size_t)n + (size_t)n * ld;
+    for (int r = tid; r < m; r += 256) {
+        for (int c = 0; c < m; ++c) {
+            double v = (r >= c) ? S[(size_t)r + (size_t)c * ld] : S[(size_t)c + (size_t)r * ld];
+            if (r == c) v += q.jitter;
+            Kn[(size_t)r + (size_t)c * ldo] = v;
+        }
+        mn[r] = -W[(size_t)nt + (size_t)(n + r) * ld];
+    }
+    if (tid == 0) *info_out = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
 // have to be fenced against an earlier asynchronous call)
 constexpr int PUT_MAX = 480;
@@ -2750,6 +2801,7 @@ static void small_lds_attr()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_ard), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_dev), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sample_derivs_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gp_condition_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     const int gbytes = SMALL_GRAD_LDS_DOUBLES * (int)sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
@@ -2779,6 +2831,7 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->small_ng1 = 128;   // tools/grad_small_bench.py: one workgroup 57 / 82 / 109 / 207 / 303 / 337 us at n = 21 / 64 / 128 / 160 / 199 / 256,
                           // the launch chain 151 / 162 / 180 / ~225 / 274 / 272; four chains at once 93 .. 363 us against 377 .. 525
     t->small_ng = 256;
+    t->small_gc = 180;    // gpmi_gp_condition by one workgroup up to n + m + 1 rows (tools/cond_bench.py)
     t->small_sd = 640;
     t->small_sdb = 5;     // tools/sample_derivs_bench.py: one workgroup 0.21 / 0.56 / 0.73 ms at n = m = 79 / 199 / 256, the lanes 95 / 136 / 129 us per draw
     t->small_n2 = 1024;
@@ -3430,6 +3483,18 @@ void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, co
     small_lds_attr();
     hipLaunchKernelGGL(k_sample_derivs_small_batch, dim3(B), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dt, n, dts, m, dY, d_par, jitter, dZ,
                        Wall, stride, ld, d_draws, d_mus, d_status, d_info_work);
+}
+
+void launch_gp_condition_small(hipStream_t s, const double *t, int n, const double *ts, int m, const double *y, int kindK, int kindS,
+                               int kindSS, int compat, double a2, double l2, double s2, double jitter, double *W, double *Kn, size_t ldo,
+                               double *mn, int *info_out, int *d_info_work, double *stage)
+{
+    size_t ld, stride;
+    small_ws_layout(n + m, &ld, &stride);
+    small_lds_attr();
+    CondArgs q{kindK, kindS, kindSS, compat, a2, l2, s2, jitter};
+    hipLaunchKernelGGL(k_gp_condition_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, t, n, ts, m, y, q, W, ld, Kn, ldo, mn,
+                       info_out, d_info_work, stage);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

@@ -411,6 +411,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         (name[8] == '1' ? c->tune.small_ng1 : c->tune.small_ng) = value;
         return 0;
     }
+    if (!strcmp(name, "small_gc")) {  // gp_condition by one workgroup up to this many rows n + m + 1 (0: off)
+        if (value < 0 || value > 1024) return gpmi_fail(GPMI_EARG, "small_gc must be 0 .. 1024");
+        c->tune.small_gc = value;
+        return 0;
+    }
     if (!strcmp(name, "small_sd")) {  // sample_derivs[_batch]: one workgroup per draw up to this many rows n + m + 1 (0: off)
         if (value < 0 || value > 1024) return gpmi_fail(GPMI_EARG, "small_sd must be 0 .. 1024");
         c->tune.small_sd = value;
@@ -2007,6 +2012,37 @@ extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const doub
         return gpmi_fail(GPMI_EARG, "bad kernel kind");
     int rc;
     const int nt = n + m, M = nt + 1;
+    if (c->tune.small_gc > 0 && M <= c->tune.small_gc) {
+        // R/tests.R sizes: ONE launch of one workgroup; t, ts, y go in and mn, Kn, info come back through a pinned,
+        // device-mapped buffer (no copy call): layout [info | mn (m) | Kn (m x m) | t | ts | y]
+        const size_t need = (8 + (size_t)m + (size_t)m * m + 2 * (size_t)n + m) * sizeof(double);
+        if (need > c->h_pin_bytes) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
+            c->h_pin = c->h_pin_dev = nullptr;
+            c->h_pin_bytes = 0;
+            const size_t want = need > 65536 ? need : 65536;
+            if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
+                return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
+            HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
+            c->h_pin_bytes = want;
+        }
+        double *hmn = c->h_pin + 8, *hKn = hmn + m, *ht = hKn + (size_t)m * m, *hts = ht + n, *hy = hts + m, *stage;
+        memcpy(ht, t, (size_t)n * sizeof(double));
+        memcpy(hts, ts, (size_t)m * sizeof(double));
+        memcpy(hy, y, (size_t)n * sizeof(double));
+        if ((rc = scratch_buf(c, (2 * (size_t)n + m) * sizeof(double), &stage))) return rc;
+        if ((rc = reserve_ws_small(c, nt, 1))) return rc;
+        double *pd = c->h_pin_dev;
+        const size_t o_mn = 8, o_Kn = o_mn + m, o_t = o_Kn + (size_t)m * m, o_ts = o_t + n, o_y = o_ts + m;
+        launch_gp_condition_small(c->stream, pd + o_t, n, pd + o_ts, m, pd + o_y, kindK, kindS, kindSS, (flags & GPMI_COMPAT_RR) ? 1 : 0,
+                                  alpha * alpha, l * l, s2, jitter, c->W, pd + o_Kn, (size_t)m, pd + o_mn, (int *)pd, c->d_info, stage);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(mn, hmn, (size_t)m * sizeof(double));
+        for (int j = 0; j < m; ++j) memcpy(Kn + (size_t)j * ldkn, hKn + (size_t)j * m, (size_t)m * sizeof(double));
+        return *(const int *)c->h_pin;
+    }
     if ((rc = reserve_ws(c, M, nt))) return rc;
     const size_t ld = (size_t)c->ld;
     double *dt, *dts, *dy, *dKn;

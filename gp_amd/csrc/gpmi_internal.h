@@ -37,6 +37,7 @@ struct gpmi_tuning {
     int small_n1;         // ... a single evaluation (or a grid of fewer than 6 points) up to this n: beyond it the multi-CU launch chain is faster
     int small_m;          // partial factorisation of <= small_m rows: one workgroup, one launch (0: off)
     int small_ng1, small_ng; // value + gradient by one workgroup: one evaluation up to n <= small_ng1, several (a sampler's chains) up to small_ng (<= 256; 0: off)
+    int small_gc;            // gpmi_gp_condition: one workgroup, one launch, up to n + m + 1 <= small_gc rows (0: off)
     int small_sd, small_sdb; // sample_derivs_batch: one workgroup per draw when n + m + 1 <= small_sd rows and at least small_sdb (n + m + 1)^2 / 400^2 draws (0: off)
     int small_n2, small_g2;  // grids of >= small_g2 (n / 1024)^2 + 2 points: one workgroup per point up to n <= small_n2 (every CU a problem of its own)
 };
@@ -183,6 +184,10 @@ void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int l
 void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, const double *dts, int m, const double *dY,
                                       const double *params, int B, double jitter, const double *dZ, double *d_par, double *Wall,
                                       double *d_draws, double *d_mus, int *d_status, int *d_info_work);
+// gp_condition by one workgroup (workspace: one slice of small_ws_layout(n + m)); t, ts, y / Kn, mn, info_out may be host-mapped (stage != null)
+void launch_gp_condition_small(hipStream_t s, const double *t, int n, const double *ts, int m, const double *y, int kindK, int kindS,
+                               int kindSS, int compat, double a2, double l2, double s2, double jitter, double *W, double *Kn, size_t ldo,
+                               double *mn, int *info_out, int *d_info_work, double *stage);
 // any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
 #define GPMI_SMALL_PAR (2 + GPMI_MAXD)
 #define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS

@@ -142,3 +142,14 @@ __device__ __forceinline__ double deriv_val(int kind, double tj, double tk, doub
                (e * r * r * r * r) / (l2 * l2 * l2 * l2);
     }
 }
+
+// alpha^2 times a derivative kernel; compat (R/kernels.R:31 as written): for RR alpha^2 multiplies the first term only
+__device__ __forceinline__ double deriv_cov_val(int kind, int compat, double a2, double x, double yv, double l2)
+{
+    if (compat && kind == GPMI_RR) {
+        const double r = x - yv;
+        const double e = exp(-(r * r / (2 * l2)));
+        return a2 * e / l2 - (e * r * r) / (l2 * l2);
+    }
+    return a2 * deriv_val(kind, x, yv, l2);
+}

@@ -134,16 +134,7 @@ __global__ __launch_bounds__(256) void k_deriv_cov(int kind, const double *__res
         const int c = col0 + ty * 8 + q;
         if (c >= m) break;
         const double yv = y[c];
-        double v0, v1;
-        if (compat && kind == GPMI_RR) {  // R/kernels.R:31 as written: alpha^2 on the first term only
-            const double r0 = x0 - yv, r1 = x1 - yv;
-            const double e0 = exp(-(r0 * r0 / (2 * l2))), e1 = exp(-(r1 * r1 / (2 * l2)));
-            v0 = a2 * e0 / l2 - (e0 * r0 * r0) / (l2 * l2);
-            v1 = a2 * e1 / l2 - (e1 * r1 * r1) / (l2 * l2);
-        } else {
-            v0 = a2 * deriv_val(kind, x0, yv, l2);
-            v1 = a2 * deriv_val(kind, x1, yv, l2);
-        }
+        const double v0 = deriv_cov_val(kind, compat, a2, x0, yv, l2), v1 = deriv_cov_val(kind, compat, a2, x1, yv, l2);
         const bool w0 = ok0 && (!lower || r >= c), w1 = ok1 && (!lower || r + 1 >= c);
         store_pair(K + (size_t)r + (size_t)c * ldk, v0, v1, w0, w1, vec != 0);
     }

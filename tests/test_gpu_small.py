@@ -130,12 +130,18 @@ def test_small_partial_factorisation_posteriors(one_wg, orc, n, m):
     Kd = K + s2 * np.eye(n)
     mn_ref = Ks @ np.linalg.solve(Kd, y)
     Kn_ref = Kss - Ks @ np.linalg.solve(Kd, Ks.T) + jit * np.eye(m)
+    ctx.set_option("small_gc", 0)     # the launch chain around the one-workgroup factorisation
     mn, Kn = ctx.gp_condition(t, ts, y, a, l, s2, jit, "QQ", "RQ", "RR")
     try:
         ctx.set_option("small_m", 0)
         mn_b, Kn_b = ctx.gp_condition(t, ts, y, a, l, s2, jit, "QQ", "RQ", "RR")
     finally:
         ctx.set_option("small_m", 640)
+        ctx.set_option("small_gc", 180)
+    if n + m + 1 <= 180:              # default: the whole call is ONE launch (k_gp_condition_small)
+        mn_f, Kn_f = ctx.gp_condition(t, ts, y, a, l, s2, jit, "QQ", "RQ", "RR")
+        assert np.max(np.abs(mn_f - mn)) <= 1e-12 * np.max(np.abs(mn)) and np.max(np.abs(Kn_f - Kn)) <= 1e-12 * np.max(np.abs(Kn))
+        assert np.array_equal(Kn_f, Kn_f.T)
     e1 = np.max(np.abs(mn - mn_ref)) / np.max(np.abs(mn_ref)); e2 = np.max(np.abs(Kn - Kn_ref)) / np.max(np.abs(Kn_ref))
     print("gp_condition n=%d m=%d one workgroup: mn rel %.2e, Kn rel %.2e; vs blocked %.2e" %
           (n, m, e1, e2, np.max(np.abs(Kn - Kn_b)) / np.max(np.abs(Kn_ref))))
@@ -276,3 +282,30 @@ def test_sample_derivs_loop_one_workgroup_per_draw(ctx, orc, n, m, B):
     assert np.max(np.abs(mus - ml)) <= 1e-11 * np.max(np.abs(ml)) and np.max(np.abs(draws - dl)) <= 1e-7 * np.max(np.abs(dl))
     print("sample_derivs n=%d m=%d B=%d, one workgroup per draw: mu rel %.1e, draw rel %.1e; vs the lanes mu %.1e draw %.1e"
           % (n, m, B, worst_mu, worst_d, np.max(np.abs(mus - ml)) / np.max(np.abs(ml)), np.max(np.abs(draws - dl)) / np.max(np.abs(dl))))
+
+
+@pytest.mark.parametrize("kinds,compat", [(("QQ", "QQ", "QQ"), False), (("QQ", "RQ", "RR"), False), (("QQ", "RQ", "RR"), True),
+                                          (("QQ", "TQ", "TT"), False)])
+def test_gp_condition_in_one_launch(ctx, orc, kinds, compat):
+    """gpmi_gp_condition at R/tests.R sizes is ONE launch (k_gp_condition_small: build, partial factorisation, mirrored
+    Schur complement + jitter and mean written straight to mapped host memory): p_Xn (QQ, QQ, QQ), p_dotXn (QQ, RQ, RR; with
+    R/kernels.R:31's amplitude slip as COMPAT_RR), second derivatives (TQ, TT) -- against the reference's formula with LU
+    solves and against the launch chain bit for bit."""
+    rng = np.random.default_rng(len(kinds[1]) + compat)
+    n, m = 21, 30
+    t = np.linspace(-2, 2, n); ts = np.sort(rng.uniform(-2, 2, m)); y = np.exp(t)
+    a, l, s2, jit = 1.3, 0.8, 0.01, 1e-8
+    from gp_amd._lib import COMPAT_RR
+    flags = COMPAT_RR if compat else 0
+    mn, Kn = ctx.gp_condition(t, ts, y, a, l, s2, jit, *kinds, flags=flags)
+    ctx.set_option("small_gc", 0)
+    try:
+        mn_c, Kn_c = ctx.gp_condition(t, ts, y, a, l, s2, jit, *kinds, flags=flags)
+    finally:
+        ctx.set_option("small_gc", 180)
+    assert np.array_equal(mn, mn_c) and np.array_equal(Kn, Kn_c)
+    if not compat:
+        K = orc.deriv_cov(kinds[0], t, t, a, l) + s2 * np.eye(n)
+        Ks = orc.deriv_cov(kinds[1], ts, t, a, l); Kss = orc.deriv_cov(kinds[2], ts, ts, a, l)
+        mn_ref = Ks @ np.linalg.solve(K, y); Kn_ref = Kss - Ks @ np.linalg.solve(K, Ks.T) + jit * np.eye(m)
+        assert np.max(np.abs(mn - mn_ref)) <= RTOL * np.max(np.abs(mn_ref)) and np.max(np.abs(Kn - Kn_ref)) <= RTOL * np.max(np.abs(Kn_ref))

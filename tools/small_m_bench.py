@@ -10,11 +10,13 @@ for n, m in ((21, 21), (79, 40), (79, 79), (100, 100), (128, 128), (199, 100), (
     t = np.linspace(0, n / 10.0, n); ts = np.linspace(0, n / 10.0, m) + 0.01
     y = np.sin(t)
     res = []
-    for sm in (1024, 0):
+    for gc, sm in ((1024, 1024), (0, 1024), (0, 0)):   # fused one-launch call; chain with the one-workgroup factorisation; chain
+        ctx.set_option("small_gc", gc)
         ctx.set_option("small_m", sm)
         ctx.gp_condition(t, ts, y, 1.0, 1.0, 0.01, 1e-8, "QQ", "RQ", "RR")
         t0 = time.perf_counter()
         for _ in range(100):
             ctx.gp_condition(t, ts, y, 1.0, 1.0, 0.01, 1e-8, "QQ", "RQ", "RR")
         res.append((time.perf_counter() - t0) / 100 * 1e6)
-    print("n=%4d m=%4d (M = %4d rows): one workgroup %7.1f us, launch chain %7.1f us per gp_condition call" % (n, m, n + m + 1, res[0], res[1]), flush=True)
+    print("n=%4d m=%4d (M = %4d rows): ONE launch (k_gp_condition_small) %7.1f us; launch chain with the factorisation in one workgroup %7.1f us, "
+          "with the blocked factorisation %7.1f us per gp_condition call" % (n, m, n + m + 1, res[0], res[1], res[2]), flush=True)
