@@ -201,7 +201,21 @@ def c1_record(ctx, dev, skip_cpu):
             ctx.sync()
             if r:
                 best = min(best, time.perf_counter() - t0)
-        e = {"N": n, "logml": float(val), "host_buffer_call_us": host_us, "grid64_us_per_eval": 1e6 * best / G,
+        grad_us = grad4_us = None
+        if n <= 256:   # value + gradient: what one leapfrog step of the reference's Stan fit asks for (one chain / rstan's four)
+            ctx.logml_grad(x, y, 1.0, [1.0], 0.1)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                ctx.logml_grad(x, y, 1.0, [1.0], 0.1)
+            grad_us = 1e6 * (time.perf_counter() - t0) / 100
+            a4 = np.ones(4); r4 = np.array([1.0, 1.1, 0.9, 1.2]); s4 = np.full(4, 0.1)
+            ctx.logml_grad_grid(x, y, a4, r4, s4)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                ctx.logml_grad_grid(x, y, a4, r4, s4)
+            grad4_us = 1e6 * (time.perf_counter() - t0) / 50
+        e = {"N": n, "logml": float(val), "host_buffer_call_us": host_us, "value_and_gradient_call_us": grad_us,
+             "value_and_gradient_four_chains_call_us": grad4_us, "grid64_us_per_eval": 1e6 * best / G,
              "grid64_evals_per_s": G / best, "grid64_results_ok": bool(np.all(info.cpu().numpy() == 0))}
         if not skip_cpu:
             from oracle import oracle as orc
