@@ -890,6 +890,22 @@ static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
 // ---- marginal likelihood -----------------------------------------------------
 // n small enough for the one-workgroup evaluation (k_logml_small): the sizes the reference's own drivers run
 // at (R/tests.R:5 N = 21, pendulum_fit*.R 79 .. 199, BASELINE c1 N = 256)
+// pinned, device-mapped host buffer of the one-launch host-buffer calls (inputs in, results out, no copy call)
+static int pin_reserve(gpmi_ctx *c, size_t need)
+{
+    if (need <= c->h_pin_bytes) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
+    c->h_pin = c->h_pin_dev = nullptr;
+    c->h_pin_bytes = 0;
+    const size_t want = need > 65536 ? need : 65536;
+    if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
+        return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
+    HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
+    c->h_pin_bytes = want;
+    return 0;
+}
+
 static bool small_logml(const gpmi_ctx *c, int n, int D, int G = 1)
 {
     // one workgroup against the multi-CU launch chain (tools/small_n_bench.py, one evaluation / 64 points, us per
@@ -1119,17 +1135,7 @@ extern "C" int gpmi_logml(gpmi_ctx *c, const double *X, int n, int ldx, int D, c
         SeParams p;
         if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
         const size_t need = (8 + (size_t)n * (D + 1)) * sizeof(double);
-        if (need > c->h_pin_bytes) {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
-            c->h_pin = c->h_pin_dev = nullptr;
-            c->h_pin_bytes = 0;
-            const size_t want = need > 65536 ? need : 65536;
-            if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
-                return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
-            HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
-            c->h_pin_bytes = want;
-        }
+        if ((rc = pin_reserve(c, need))) return rc;
         double *hX = c->h_pin + 8, *hy = hX + (size_t)n * D, *stage;
         for (int d = 0; d < D; ++d) memcpy(hX + (size_t)d * n, X + (size_t)d * ldx, (size_t)n * sizeof(double));
         memcpy(hy, y, (size_t)n * sizeof(double));
@@ -1514,7 +1520,8 @@ static int approx_Lz_core(gpmi_ctx *c, double l, const double *dz, double *df, d
     const int n = c->itp_n;
     const int k = interp_interval(c, l);
     const size_t msz = c->itp_ld * n;
-    HIPCHK(hipMemsetAsync(c->itp_part, 0, (ddfdl ? 2 : 1) * (size_t)hermite_mv_chunks(n) * n * sizeof(double), c->stream));
+    if (n > GPMI_HMV_SMALL_N)   // (the one-launch form of small n keeps its chunk sums in registers)
+        HIPCHK(hipMemsetAsync(c->itp_part, 0, (ddfdl ? 2 : 1) * (size_t)hermite_mv_chunks(n) * n * sizeof(double), c->stream));
     launch_hermite_mv(c->stream, c->itp_L + k * msz, c->itp_L + (k + 1) * msz, c->itp_dL + k * msz,
                       c->itp_dL + (k + 1) * msz, c->itp_ld, n, c->itp_lp[k], c->itp_lp[k + 1], l, dz, c->itp_part, df, ddfdl);
     HIPCHK(hipGetLastError());
@@ -1542,6 +1549,24 @@ static int approx_Lz_host(gpmi_ctx *c, double l, const double *z, double *f, dou
     int rc;
     double *dz;
     if ((rc = stage_buf(c, 0, 3 * (size_t)n * sizeof(double), &dz))) return rc;
+    if (n <= 4096) {
+        // the per-iteration call of the interpolated model at the reference's size (N = 100, test_interpolate.R:5): z goes in
+        // and f (dfdl) come back through the pinned, device-mapped buffer -- three small launches, no copy call
+        const size_t need = (3 * (size_t)n + 8) * sizeof(double);
+        if ((rc = pin_reserve(c, need))) return rc;
+        memcpy(c->h_pin, z, (size_t)n * sizeof(double));
+        double *pd = c->h_pin_dev;
+        const double *zsrc = pd;
+        if (n > GPMI_HMV_SMALL_N) {   // the chunked kernels read z once per row block: staged in device memory first
+            launch_copy_matrix(c->stream, pd, (size_t)n, dz, (size_t)n, n, 1, 0);
+            zsrc = dz;
+        }
+        if ((rc = approx_Lz_core(c, l, zsrc, pd + n, dfdl ? pd + 2 * (size_t)n : nullptr))) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        memcpy(f, c->h_pin + n, (size_t)n * sizeof(double));
+        if (dfdl) memcpy(dfdl, c->h_pin + 2 * (size_t)n, (size_t)n * sizeof(double));
+        return 0;
+    }
     HIPCHK(hipMemcpyAsync(dz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if ((rc = approx_Lz_core(c, l, dz, dz + n, dfdl ? dz + 2 * (size_t)n : nullptr))) return rc;
     HIPCHK(hipMemcpyAsync(f, dz + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1864,17 +1889,7 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
         // the sizes the reference's fits run at: ONE launch of one workgroup; X, y go in and the 13 results come back
         // through a pinned, device-mapped buffer (no copy call), as in gpmi_logml
         const size_t need = (16 + (size_t)n * (D + 1)) * sizeof(double);
-        if (need > c->h_pin_bytes) {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
-            c->h_pin = c->h_pin_dev = nullptr;
-            c->h_pin_bytes = 0;
-            const size_t want = need > 65536 ? need : 65536;
-            if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
-                return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
-            HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
-            c->h_pin_bytes = want;
-        }
+        if ((rc = pin_reserve(c, need))) return rc;
         double *hX = c->h_pin + 16, *hy = hX + (size_t)n * D, *stage;
         for (int d = 0; d < D; ++d) memcpy(hX + (size_t)d * n, X + (size_t)d * ldx, (size_t)n * sizeof(double));
         memcpy(hy, y, (size_t)n * sizeof(double));
@@ -2016,17 +2031,7 @@ extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const doub
         // R/tests.R sizes: ONE launch of one workgroup; t, ts, y go in and mn, Kn, info come back through a pinned,
         // device-mapped buffer (no copy call): layout [info | mn (m) | Kn (m x m) | t | ts | y]
         const size_t need = (8 + (size_t)m + (size_t)m * m + 2 * (size_t)n + m) * sizeof(double);
-        if (need > c->h_pin_bytes) {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            if (c->h_pin) HIPCHK(hipHostFree(c->h_pin));
-            c->h_pin = c->h_pin_dev = nullptr;
-            c->h_pin_bytes = 0;
-            const size_t want = need > 65536 ? need : 65536;
-            if (hipHostMalloc((void **)&c->h_pin, want, hipHostMallocMapped) != hipSuccess)
-                return gpmi_fail(GPMI_ENOMEM, "cannot allocate %zu bytes of pinned host memory", want);
-            HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
-            c->h_pin_bytes = want;
-        }
+        if ((rc = pin_reserve(c, need))) return rc;
         double *hmn = c->h_pin + 8, *hKn = hmn + m, *ht = hKn + (size_t)m * m, *hts = ht + n, *hy = hts + m, *stage;
         memcpy(ht, t, (size_t)n * sizeof(double));
         memcpy(hts, ts, (size_t)m * sizeof(double));

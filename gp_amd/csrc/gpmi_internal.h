@@ -142,6 +142,7 @@ void launch_hermite_mv(hipStream_t s, const double *L1, const double *L2, const 
                        size_t ld, int n, double x1, double x2, double l, const double *z, double *part, double *f,
                        double *dfdl /* nullable: (dv/dl) z, the reverse-mode partial of approx_Lz */);
 int hermite_mv_chunks(int n);
+#define GPMI_HMV_SMALL_N 256    // approx_Lz up to this n: one launch, z read straight from (possibly host-mapped) memory
 void launch_phi_mask(hipStream_t s, double *B, size_t ld, int n); // keep upper, halve diag, zero strict lower
 
 // ---- kernel launchers (chol_kernels.hip) -----------------------------------

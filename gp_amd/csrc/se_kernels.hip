@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void k_hermite_blend(const double *__restrict_
 // approx_Lz (build_output's `var` overload, models/cubic_interpolated_gp.hpp:6-32; dvdl as written at
 // :67) -- into partg: no extra HBM traffic, the four triangles are read once.
 constexpr int HMV_CW = 128;
+constexpr int HMV_SMALL_N = GPMI_HMV_SMALL_N;  // up to here blend + mat-vec is one launch (k_hermite_mv_small)
 template <bool GRAD>
 __global__ __launch_bounds__(256) void k_hermite_mv(const double *__restrict__ L1, const double *__restrict__ L2,
                                                     const double *__restrict__ D1, const double *__restrict__ D2,
@@ -320,6 +321,56 @@ __global__ __launch_bounds__(256) void k_hermite_mv(const double *__restrict__ L
     }
     part[(size_t)blockIdx.y * n + i] = acc;
     if constexpr (GRAD) partg[(size_t)blockIdx.y * n + i] = accg;
+}
+
+// The same blend + mat-vec for small n in ONE launch (the per-iteration call of the interpolated model at the reference's
+// N = 100): thread = row, z staged in LDS by the workgroup (z may be host-mapped: read once), the row's 128-column chunk sums
+// formed and added in chunk order -- the additions of k_hermite_mv + k_hermite_mv_sum in the same order (bit-identical) --
+// with eight columns (32 loads) in flight per round trip.
+template <bool GRAD>
+__global__ __launch_bounds__(256) void k_hermite_mv_small(const double *__restrict__ L1, const double *__restrict__ L2,
+                                                          const double *__restrict__ D1, const double *__restrict__ D2,
+                                                          size_t ld, int n, double dx, double t, double dtdl,
+                                                          const double *__restrict__ z, double *__restrict__ f,
+                                                          double *__restrict__ fg)
+{
+    extern __shared__ double szs[];
+    for (int j = threadIdx.x; j < n; j += 256) szs[j] = z[j];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double tot = 0.0, totg = 0.0;
+    for (int j0 = 0; j0 <= i; j0 += HMV_CW) {
+        const int jend = (i + 1 < j0 + HMV_CW) ? i + 1 : j0 + HMV_CW;
+        double acc = 0.0, accg = 0.0;
+        for (int jb = j0; jb < jend; jb += 8) {
+            double y1[8], y2[8], k1[8], k2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + q < jend ? jb + q : jend - 1;
+                const size_t o = (size_t)i + (size_t)j * ld;
+                y1[q] = L1[o];
+                y2[q] = L2[o];
+                k1[q] = D1[o];
+                k2[q] = D2[o];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (jb + q < jend) {
+                    acc += hermite(y1[q], y2[q], k1[q], k2[q], dx, t) * szs[jb + q];
+                    if constexpr (GRAD) {
+                        const double a = k1[q] * dx - (y2[q] - y1[q]);
+                        const double b = -k2[q] * dx + (y2[q] - y1[q]);
+                        accg += ((b * (2 - 3 * t) * t + a * (1 + t * (-4 + 3 * t)) - y1[q] + y2[q]) * dtdl) * szs[jb + q];
+                    }
+                }
+            }
+        }
+        tot += acc;
+        if constexpr (GRAD) totg += accg;
+    }
+    f[i] = tot;
+    if constexpr (GRAD) fg[i] = totg;
 }
 
 __global__ void k_hermite_mv_sum(const double *__restrict__ part, int n, int nchunks, double *__restrict__ f)
@@ -432,6 +483,14 @@ void launch_hermite_mv(hipStream_t s, const double *L1, const double *L2, const 
     if (n <= 0) return;
     const double t = (l - x1) / (x2 - x1);
     const double dtdl = 1 / (x2 - x1);
+    if (n <= HMV_SMALL_N) {  // one launch; `part` is not used
+        const dim3 g1((n + 255) / 256);
+        if (dfdl)
+            hipLaunchKernelGGL(k_hermite_mv_small<true>, g1, 256, (size_t)n * sizeof(double), s, L1, L2, D1, D2, ld, n, x2 - x1, t, dtdl, z, f, dfdl);
+        else
+            hipLaunchKernelGGL(k_hermite_mv_small<false>, g1, 256, (size_t)n * sizeof(double), s, L1, L2, D1, D2, ld, n, x2 - x1, t, dtdl, z, f, dfdl);
+        return;
+    }
     const int nch = hermite_mv_chunks(n);
     double *partg = part + (size_t)nch * n;
     const dim3 grid((n + 255) / 256, nch);
