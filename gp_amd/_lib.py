@@ -20,7 +20,7 @@ SYMBOLS = (
     "gpmi_version", "gpmi_last_error", "gpmi_device_count", "gpmi_create", "gpmi_destroy",
     "gpmi_set_stream", "gpmi_reset_stream", "gpmi_sync", "gpmi_reserve", "gpmi_set_option",
     "gpmi_se_cov", "gpmi_se_cov_dev", "gpmi_deriv_cov", "gpmi_deriv_cov_dev", "gpmi_deriv_elem",
-    "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower",
+    "gpmi_joint_cov", "gpmi_potrf", "gpmi_potrf_dev", "gpmi_trmv_lower", "gpmi_trsv_lower", "gpmi_exact_gp_f",
     "gpmi_logml", "gpmi_logml_dev", "gpmi_logml_grid", "gpmi_logml_grid_dev", "gpmi_logml_grid_ard", "gpmi_logml_grid_ard_dev",
     "gpmi_joint_logml", "gpmi_joint_logml_dev", "gpmi_joint_logml_grid_dev", "gpmi_rbf_cov_chol", "gpmi_gp_condition", "gpmi_sample_derivs", "gpmi_sample_derivs_batch",
     "gpmi_interp_build", "gpmi_interp_load", "gpmi_approx_L", "gpmi_approx_Lz", "gpmi_approx_Lz_dev", "gpmi_approx_Lz_grad", "gpmi_approx_Lz_grad_dev",
@@ -246,6 +246,17 @@ class Context:
         L = _mat(L); b = _vec(b); z = np.empty_like(b)
         _chk(self._lib.gpmi_trsv_lower(self._h, _p(L), L.shape[0], max(L.shape[0], 1), _p(b), _p(z)))
         return z
+
+    def exact_gp_f(self, X, alpha, ell, z, jitter=1e-10):
+        """f = chol(cov_exp_quad(X, alpha, ell) + jitter I) z (models/exact_gp.stan:17-25), fused on the device; raises
+        NotPositiveDefinite."""
+        X = _mat(X); z = _vec(z); ell = _vec(ell)
+        n, D = X.shape
+        if z.size != n:
+            raise GpmiError(-1, "X and z disagree on N")
+        f = np.empty(n)
+        _chk(self._lib.gpmi_exact_gp_f(self._h, _p(X), n, n, D, _d(alpha), _p(ell), int(ell.size), _d(jitter), _p(z), _p(f)))
+        return f
 
     # ---- marginal likelihood -------------------------------------------------
     def logml(self, X, y, alpha, ell, sigma, jitter=0.0):

@@ -2479,6 +2479,76 @@ __global__ __launch_bounds__(256, 2) void k_gp_condition_small(const double *__r
     if (tid == 0) *info_out = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// f = chol(cov_exp_quad(X, alpha, ell) + diag_add I) z (models/exact_gp.stan:17-25: the latent exact GP's transform, once per
+// leapfrog step with a new length-scale) by ONE workgroup for n <= 256: build (se_cov_tile), factorisation, and the row sums
+// f_i = sum_{j <= i} L_ij z_j in column order (the order of k_trmv_lower_part inside its first chunk).  stage (nullable): X, z
+// host-mapped -> copied to device memory first; f / info_out may be host-mapped.
+__global__ __launch_bounds__(256, 2) void k_exact_gp_small(const double *__restrict__ X, int n, int ldx, const double *__restrict__ z,
+                                                        SeParams p, double diag_add, double *__restrict__ W, size_t ld,
+                                                        double *__restrict__ f, int *info_out, int *info_w, ExpC ec,
+                                                        double *__restrict__ stage)
+{
+    GPMI_SMALL_LDS
+    const int tid = threadIdx.x;
+    if (stage) {
+        const int nx = n * p.D;
+        for (int e = tid; e < nx + n; e += 256) {
+            const int d = e / n, i = e - d * n;
+            stage[e] = (e < nx) ? X[(size_t)i + (size_t)d * ldx] : z[e - nx];
+        }
+        __syncthreads();
+        X = stage;
+        z = stage + nx;
+        ldx = n;
+    }
+    if (tid == 0) *info_w = 0;
+    SmallSe se;
+    se.a2 = p.a2;
+    se.D = p.D;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = p.inv_ell[d];
+    {
+        double *xs = &smem[0][0][0][0];
+#pragma unroll
+        for (int d = 0; d < GPMI_MAXD; ++d)
+            if (d < se.D)
+                for (int i = tid; i < n; i += 256) xs[i + d * n] = __dmul_rn(X[(size_t)i + (size_t)d * ldx], se.inv_ell[d]);
+        __syncthreads();
+        for (int row0 = 0; row0 < n; row0 += SE_TR)
+            for (int col0 = 0; col0 < row0 + SE_TR && col0 < n; col0 += SE_TC) {
+                switch (se.D) {
+                case 1: se_cov_tile<1, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                case 2: se_cov_tile<2, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                case 3: se_cov_tile<3, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                default: se_cov_tile<0, true>(xs, n, n, xs, n, n, se, diag_add, 1, 1, W, ld, 1, ec, row0, col0); break;
+                }
+            }
+    }
+    __syncthreads();
+    small_potrf_partial(smem, s_F, s_aux, W, ld, n, n, n, info_w, false);
+    __syncthreads();
+    if (tid < n) s_aux[tid] = z[tid];
+    __syncthreads();
+    if (tid < n) {
+        const int i = tid;
+        double acc = 0.0;
+        for (int j0 = 0; j0 <= i; j0 += 16) {
+            double u[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int j = j0 + q <= i ? j0 + q : i;
+                u[q] = W[(size_t)i + (size_t)j * ld];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (j0 + q <= i) acc = fma(u[q], s_aux[j0 + q], acc);
+        }
+        const int info = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f[i] = info ? __builtin_nan("") : acc;
+    }
+    if (tid == 0) *info_out = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
 // have to be fenced against an earlier asynchronous call)
 constexpr int PUT_MAX = 480;
@@ -2802,6 +2872,7 @@ static void small_lds_attr()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_small_batch_dev), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sample_derivs_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gp_condition_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_exact_gp_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     const int gbytes = SMALL_GRAD_LDS_DOUBLES * (int)sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
@@ -3495,6 +3566,16 @@ void launch_gp_condition_small(hipStream_t s, const double *t, int n, const doub
     CondArgs q{kindK, kindS, kindSS, compat, a2, l2, s2, jitter};
     hipLaunchKernelGGL(k_gp_condition_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, t, n, ts, m, y, q, W, ld, Kn, ldo, mn,
                        info_out, d_info_work, stage);
+}
+
+void launch_exact_gp_small(hipStream_t s, const double *X, int n, int ldx, const double *z, const SeParams &p, double diag_add,
+                           double *W, double *f, int *info_out, int *d_info_work, double *stage)
+{
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_exact_gp_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, X, n, ldx, z, p, diag_add, W, ld, f, info_out,
+                       d_info_work, h_exp, stage);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

@@ -887,6 +887,55 @@ static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
     }
 }
 
+// ---- latent exact GP: f = chol(K) z --------------------------------------------------------
+static int pin_reserve(gpmi_ctx *c, size_t need);
+static int reserve_ws_small(gpmi_ctx *c, int n, int count);
+static int upload_xy(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y, double **dX, double **dy);
+extern "C" int gpmi_exact_gp_f(gpmi_ctx *c, const double *X, int n, int ldx, int D, double alpha, const double *ell, int n_ell,
+                               double jitter, const double *z, double *f)
+{
+    ENTER(c);
+    if (n <= 0 || !X || !z || !f || ldx < n || D < 1) return gpmi_fail(GPMI_EARG, "bad argument");
+    SeParams p;
+    int rc;
+    if ((rc = fill_params(&p, D, alpha, ell, n_ell))) return rc;
+    hipStream_t s = c->stream;
+    if (n <= 256 && D <= GPMI_MAXD) {
+        // one launch of one workgroup; X, z in and f, info out through the pinned, device-mapped buffer: [info | f | X | z]
+        const size_t need = (8 + (size_t)n * (D + 2)) * sizeof(double);
+        if ((rc = pin_reserve(c, need))) return rc;
+        double *hf = c->h_pin + 8, *hX = hf + n, *hz = hX + (size_t)n * D, *stage;
+        for (int d = 0; d < D; ++d) memcpy(hX + (size_t)d * n, X + (size_t)d * ldx, (size_t)n * sizeof(double));
+        memcpy(hz, z, (size_t)n * sizeof(double));
+        if ((rc = scratch_buf(c, (size_t)n * (D + 1) * sizeof(double), &stage))) return rc;
+        if ((rc = reserve_ws_small(c, n, 1))) return rc;
+        double *pd = c->h_pin_dev;
+        launch_exact_gp_small(s, pd + 8 + n, n, n, pd + 8 + n + (size_t)n * D, p, jitter, c->W, pd + 8, (int *)pd, c->d_info, stage);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        memcpy(f, hf, (size_t)n * sizeof(double));
+        return *(const int *)c->h_pin;
+    }
+    double *dX, *dz;
+    if ((rc = upload_xy(c, X, n, ldx, D, z, &dX, &dz))) return rc;
+    if ((rc = reserve_ws(c, n, n))) return rc;
+    const size_t ld = (size_t)c->ld;
+    double *part;
+    if ((rc = stage_buf(c, 3, ((size_t)trmv_lower_chunks(n) + 1) * n * sizeof(double), &part))) return rc;
+    double *df = part + (size_t)trmv_lower_chunks(n) * n;
+    HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+    launch_se_cov(c, s, dX, n, n, nullptr, n, n, p, jitter, 1, c->W, ld);
+    if ((rc = launch_potrf_partial(c, c->W, ld, n, n, n, c->d_info, nullptr))) return rc;
+    launch_trmv_lower(s, c->W, ld, n, dz, df, part);
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(f, df, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&info, c->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (info)
+        for (int i = 0; i < n; ++i) f[i] = NAN;
+    return info;
+}
+
 // ---- marginal likelihood -----------------------------------------------------
 // n small enough for the one-workgroup evaluation (k_logml_small): the sizes the reference's own drivers run
 // at (R/tests.R:5 N = 21, pendulum_fit*.R 79 .. 199, BASELINE c1 N = 256)
@@ -922,8 +971,6 @@ static bool small_logml(const gpmi_ctx *c, int n, int D, int G = 1)
     }
     return lim > 0 && n <= lim && n <= GPMI_SMALL_NMAX && D <= GPMI_MAXD;
 }
-
-static int reserve_ws_small(gpmi_ctx *c, int n, int count);
 
 // device buffers of the device-parameter small-N grid: parameters and one work int per point
 static int reserve_small_par(gpmi_ctx *c, int G)

@@ -189,6 +189,9 @@ void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, co
 void launch_gp_condition_small(hipStream_t s, const double *t, int n, const double *ts, int m, const double *y, int kindK, int kindS,
                                int kindSS, int compat, double a2, double l2, double s2, double jitter, double *W, double *Kn, size_t ldo,
                                double *mn, int *info_out, int *d_info_work, double *stage);
+// f = chol(K + diag_add I) z by one workgroup (n <= 256, D <= GPMI_MAXD); X, z / f, info_out may be host-mapped (stage != null)
+void launch_exact_gp_small(hipStream_t s, const double *X, int n, int ldx, const double *z, const SeParams &p, double diag_add,
+                           double *W, double *f, int *info_out, int *d_info_work, double *stage);
 // any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
 #define GPMI_SMALL_PAR (2 + GPMI_MAXD)
 #define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS

@@ -87,6 +87,4 @@ def exact_gp_f(x, l, z, ctx=None):
     """f = L z with L = chol(cov_exp_quad(x, 1, l) + 1e-10 I) -- models/exact_gp.stan:17-25."""
     c = ctx or default_context()
     x = np.asarray(x, float).reshape(len(z), -1)
-    K = c.se_cov(x, None, 1.0, l, diag_add=1e-10)
-    L = c.potrf(K)
-    return c.trmv_lower(L, z)
+    return c.exact_gp_f(x, 1.0, [l], z, 1e-10)   # covariance, factor and product stay on the device (gpmi_exact_gp_f)

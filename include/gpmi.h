@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GPMI_VERSION 301
+#define GPMI_VERSION 302
 
 /* the ABI: the ONLY symbols libgpmi.so exports (it is built with -fvisibility=hidden) */
 #define GPMI_API __attribute__((visibility("default")))
@@ -139,6 +139,12 @@ GPMI_API int gpmi_potrf_dev(gpmi_ctx *ctx, double *dA, int n, int lda, int *d_in
  * multi_normal_cholesky, models/fit_hyperparameters.stan:31). */
 GPMI_API int gpmi_trmv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *z, double *f);
 GPMI_API int gpmi_trsv_lower(gpmi_ctx *ctx, const double *L, int n, int ldl, const double *b, double *z);
+/* The latent exact GP's transform in ONE call, models/exact_gp.stan:17-25 (test_interpolate.R:31-36 runs it at N = 100):
+ * f = cholesky_decompose(cov_exp_quad(X, alpha, ell) + jitter I) z -- covariance, factor and product stay on the
+ * device, only z goes in and f comes out (n <= 256: one launch of one workgroup).  Returns 0, or the order of the first
+ * non-positive leading minor (f is NaN then). */
+GPMI_API int gpmi_exact_gp_f(gpmi_ctx *ctx, const double *X, int n, int ldx, int D, double alpha, const double *ell, int n_ell,
+                    double jitter, const double *z, double *f);
 
 /* ---- marginal likelihood ---------------------------------------------- */
 

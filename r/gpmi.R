@@ -78,6 +78,10 @@ gp_interp_Lz <- function(l, z) {
   .Call("gpmi_R_approx_Lz", l, numeric(0), NULL, NULL, as.double(z))
 }
 
+# models/exact_gp.stan:17-25: f = cholesky_decompose(cov_exp_quad(x, alpha, rho) + 1e-10 I) * z, fused on the device
+gp_exact_f <- function(X, alpha, rho, z, jitter = 1e-10)
+  .Call("gpmi_R_exact_gp_f", as.matrix(X), alpha, as.double(rho), jitter, as.double(z))
+
 # models/fit_hyperparameters.stan:18-32 as plain functions
 gp_log_marginal <- function(X, y, alpha, rho, sigma, jitter = 0)
   .Call("gpmi_R_logml", as.matrix(X), as.double(y), alpha, as.double(rho), sigma, jitter)[1]

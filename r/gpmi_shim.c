@@ -208,6 +208,21 @@ SEXP gpmi_R_logml(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)
     return out;
 }
 
+/* f = cholesky_decompose(cov_exp_quad(X, alpha, ell) + jitter I) z: the transform of models/exact_gp.stan:17-25 */
+SEXP gpmi_R_exact_gp_f(SEXP X, SEXP alpha, SEXP ell, SEXP jitter, SEXP z)
+{
+    int n = Rf_nrows(X), D = Rf_ncols(X);
+    need(is_real(X) && is_real(z) && is_real(ell), "X, z and the length-scales must be double");
+    need(Rf_length(z) == n, "length(z) must equal nrow(X)");
+    need(Rf_length(ell) == 1 || Rf_length(ell) == D, "length-scale must have length 1 or ncol(X)");
+    SEXP out = PROTECT(Rf_allocVector(REALSXP, n));
+    int rc = gpmi_exact_gp_f(ctx(), REAL(X), n, n, D, Rf_asReal(alpha), REAL(ell), Rf_length(ell), Rf_asReal(jitter), REAL(z),
+                             REAL(out));
+    UNPROTECT(1);
+    check(rc);
+    return out;
+}
+
 /* list(value = c(logml, sum log L_ii, z'z), grad = c(d/dalpha, d/dell..., d/dsigma)): what Stan's
  * autodiff computes per leapfrog step for models/fit_hyperparameters.stan:18-32 */
 SEXP gpmi_R_logml_grad(SEXP X, SEXP y, SEXP alpha, SEXP ell, SEXP sigma, SEXP jitter)

@@ -37,7 +37,7 @@ def test_build_and_exports():
     assert not re.findall(r" T (launch_|_Z\w*launch_|_Z\w*gemm8|_Z\w*gemm9)", out)
     assert sorted(_lib.SYMBOLS) == declared  # python binding covers the whole header
     h = _lib.load()
-    assert h.gpmi_version() == 301
+    assert h.gpmi_version() == 302
     # gfx950 code object is embedded
     assert b"gfx950" in open(lib, "rb").read()
 

@@ -309,3 +309,24 @@ def test_gp_condition_in_one_launch(ctx, orc, kinds, compat):
         Ks = orc.deriv_cov(kinds[1], ts, t, a, l); Kss = orc.deriv_cov(kinds[2], ts, ts, a, l)
         mn_ref = Ks @ np.linalg.solve(K, y); Kn_ref = Kss - Ks @ np.linalg.solve(K, Ks.T) + jit * np.eye(m)
         assert np.max(np.abs(mn - mn_ref)) <= RTOL * np.max(np.abs(mn_ref)) and np.max(np.abs(Kn - Kn_ref)) <= RTOL * np.max(np.abs(Kn_ref))
+
+
+@pytest.mark.parametrize("n,D", [(1, 1), (30, 1), (100, 1), (256, 3), (257, 2), (700, 1)])
+def test_exact_gp_transform_in_one_call(ctx, orc, n, D):
+    """gpmi_exact_gp_f: f = cholesky_decompose(cov_exp_quad(x, alpha, rho) + jitter I) z (models/exact_gp.stan:17-25; the
+    reference runs it at N = 100, test_interpolate.R:31-36) -- one launch of one workgroup up to n = 256, the device chain
+    beyond -- against the oracle's Cholesky and against the composition of the separate entry points."""
+    rng = np.random.default_rng(n)
+    X = np.asfortranarray(rng.uniform(0, 1.0 + n / 8.0, (n, D))); z = rng.standard_normal(n)
+    a, l, jit = 1.3, 0.6, 1e-6
+    f = ctx.exact_gp_f(X, a, [l], z, jit)
+    Lw = orc.cholesky(orc.cov_exp_quad(X, a, l) + jit * np.eye(n))
+    want = Lw @ z
+    assert np.max(np.abs(f - want)) <= 1e-8 * np.max(np.abs(want))     # cond(K + 1e-6 I) ~ 1e6
+    K = ctx.se_cov(X, None, a, [l], diag_add=jit)
+    comp = ctx.trmv_lower(ctx.potrf(K), z)
+    assert np.max(np.abs(f - comp)) <= 1e-9 * np.max(np.abs(comp))
+    if n == 30:
+        from gp_amd import NotPositiveDefinite
+        with pytest.raises(NotPositiveDefinite):
+            ctx.exact_gp_f(np.zeros((n, 1)), 1.0, [1.0], z, 0.0)
