@@ -97,6 +97,29 @@ __device__ __forceinline__ void se_cov_tile(const double *__restrict__ X, int n,
             }
         }
     }
+    // Interior tiles (wholly inside the matrix and, for the lower triangle, wholly below the diagonal -- 98 % of the tiles
+    // at N = 16384): no bounds, no diagonal, no per-element predicates around the stores.  The build is VALU-bound, not
+    // HBM-bound (~80 instructions per element, 30 of them double-precision, against 8 bytes stored), and a quarter of the
+    // instructions were exec-mask bookkeeping of the guarded form.
+    if ((vec & 2) && row0 + SE_TR <= n && col0 + SE_TC <= m && (!same || col0 + SE_TC <= row0)) {  // workgroup-uniform
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = col0 + ty * 8 + q;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int d = 0; d < GPMI_MAXD; ++d) {
+                if (d < D) {
+                    const double yv = SCALED ? Y[(size_t)c + (size_t)d * ldy] : __dmul_rn(Y[(size_t)c + (size_t)d * ldy], p.inv_ell[d]);
+                    const double d0 = __dsub_rn(x0[d], yv), d1 = __dsub_rn(x1[d], yv);
+                    s0 = fma(d0, d0, s0);
+                    s1 = fma(d1, d1, s1);
+                }
+            }
+            const double v0 = p.a2 * exp_nonpos(-0.5 * s0, ec), v1 = p.a2 * exp_nonpos(-0.5 * s1, ec);
+            store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, true, true, true);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = col0 + ty * 8 + q;
