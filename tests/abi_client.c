@@ -5,7 +5,8 @@
  *     gcc -O2 -Iinclude tests/abi_client.c -Lgp_amd/csrc -lgpmi -lm -Wl,-rpath,$PWD/gp_amd/csrc
  * Checks the known answers K1 (the R/tests.R:5 grid t = -2, -1.8, ..., 2 with y = exp(t);
  * tests/golden/kat.json, confirmed with mpmath at 50 digits) and K2 (c1-shaped N = 256) through
- * gpmi_logml, the non-positive-definite status code, and the QQ / RR kernels of R/kernels.R.
+ * gpmi_logml, the non-positive-definite status code, the QQ / RR kernels of R/kernels.R, value + gradient, a grid, and the
+ * latent exact GP's transform.
  */
 #include <math.h>
 #include <stdio.h>
@@ -68,6 +69,51 @@ int main(void)
     CHECK(rc == 0 && fabs(K - a * a * e) <= 1e-14, "QQ %.17g", K);
     rc = gpmi_deriv_cov(ctx, GPMI_RR, &xa, 1, &xb, 1, a, l, GPMI_FULL, &K, 1);
     CHECK(rc == 0 && fabs(K - a * a * e * (1 / (l * l) - r * r / (l * l * l * l))) <= 1e-13, "RR %.17g", K);
+
+    /* value + gradient (one launch of one workgroup at this size) against central differences of the value */
+    {
+        double g[3], v3[3], vp[3], vm[3];
+        const double al = 1.1, rho = 0.9, sg = 0.07, h = 1e-6;
+        double rr = rho;
+        rc = gpmi_logml_grad(ctx, t, 21, 21, 1, y, al, &rr, 1, sg, 0.0, v3, g);
+        CHECK(rc == 0, "logml_grad status %d (%s)", rc, gpmi_last_error());
+        rr = rho + h; gpmi_logml(ctx, t, 21, 21, 1, y, al, &rr, 1, sg, 0.0, vp);
+        rr = rho - h; gpmi_logml(ctx, t, 21, 21, 1, y, al, &rr, 1, sg, 0.0, vm);
+        const double fd = (vp[0] - vm[0]) / (2 * h);
+        CHECK(fabs(g[1] - fd) <= 1e-5 * (1.0 + fabs(fd)), "d logml / d rho %.10g vs central difference %.10g", g[1], fd);
+        rr = rho;
+        gpmi_logml(ctx, t, 21, 21, 1, y, al, &rr, 1, sg, 0.0, vp);
+        CHECK(v3[0] == vp[0], "value of logml_grad %.17g != logml %.17g", v3[0], vp[0]);
+        /* a grid of three points equals three single evaluations bit for bit */
+        double ga[3] = {1.0, 1.1, 0.9}, gr[3] = {0.8, 0.9, 1.2}, gs[3] = {0.05, 0.07, 0.1}, go[9];
+        int gi[3];
+        rc = gpmi_logml_grid(ctx, t, 21, 21, 1, y, ga, gr, gs, 3, 0.0, go, gi);
+        CHECK(rc == 0 && gi[0] == 0 && gi[1] == 0 && gi[2] == 0, "grid status %d", rc);
+        for (int k = 0; k < 3; ++k) {
+            gpmi_logml(ctx, t, 21, 21, 1, y, ga[k], &gr[k], 1, gs[k], 0.0, vp);
+            CHECK(go[3 * k] == vp[0], "grid point %d: %.17g vs %.17g", k, go[3 * k], vp[0]);
+        }
+    }
+
+    /* the latent exact GP's transform (models/exact_gp.stan:17-25): n = 1 is sqrt(alpha^2 + jitter) z; n = 21 against
+     * f = L z composed from the separate entry points */
+    {
+        double x1 = 0.5, z1 = -2.0, f1 = 0.0, one = 1.0;
+        rc = gpmi_exact_gp_f(ctx, &x1, 1, 1, 1, 1.5, &one, 1, 0.25, &z1, &f1);
+        CHECK(rc == 0 && fabs(f1 - sqrt(1.5 * 1.5 + 0.25) * z1) <= 1e-15 * 4, "exact_gp_f n = 1: %.17g", f1);
+        double Kc[21 * 21], zz[21], ff[21], fc[21];
+        for (int i = 0; i < 21; ++i) zz[i] = sin(1.0 + i);
+        rc = gpmi_exact_gp_f(ctx, t, 21, 21, 1, 1.0, &one, 1, 1e-6, zz, ff);
+        CHECK(rc == 0, "exact_gp_f status %d", rc);
+        rc = gpmi_se_cov(ctx, t, 21, 21, NULL, 0, 0, 1, 1.0, &one, 1, 1e-6, GPMI_FULL, Kc, 21);
+        CHECK(rc == 0, "se_cov status %d", rc);
+        rc = gpmi_potrf(ctx, Kc, 21, 21);
+        CHECK(rc == 0, "potrf status %d", rc);
+        rc = gpmi_trmv_lower(ctx, Kc, 21, 21, zz, fc);
+        double worst = 0.0;
+        for (int i = 0; i < 21; ++i) worst = fmax(worst, fabs(ff[i] - fc[i]));
+        CHECK(rc == 0 && worst <= 1e-9, "exact_gp_f vs potrf + trmv: %.3g", worst);
+    }
 
     /* bad argument: status, message, context still usable */
     rc = gpmi_logml(ctx, t, 21, 21, 1, y, 1.0, &ell, 3, 0.05, 0.0, out);
