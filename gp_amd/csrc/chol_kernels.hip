@@ -217,6 +217,9 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
                                                  int tid = (int)threadIdx.x)
 {
     if (FULL) nblk = 8;
+    // ragged blocks: block-rows >= nblk are identity padding -- not loaded, solved, updated or stored (at n = 21 two of
+    // eight block-rows exist; carrying the padding through every step was half of the body's time there)
+#define GPMI_ACT(br) (FULL || (br) < nblk)
     double (*s_pub)[8][256] = reinterpret_cast<double (*)[8][256]>(sm);
     double (*s_inv)[256] = reinterpret_cast<double (*)[256]>(sm + 2 * 8 * 256);
     // the diagonal tile travels to the factor wave and comes back as L16 through s_d16[kb & 1]: two
@@ -273,7 +276,8 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
 #define GPMI_LOAD_TILE(T, br, jb, PR)                                                                  \
     {                                                                                                  \
         T[jb] = d4{0.0, 0.0, 0.0, 0.0};                                                                \
-        if (FULL && (jb) < (br)) {                                                                     \
+        if (!GPMI_ACT(br)) {                                                                           \
+        } else if (FULL && (jb) < (br)) {                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) T[jb][i] = ld_blk<COH>(PR + (size_t)((jb) * 16 + 4 * i) * lda); \
         } else if ((jb) <= (br)) {                                                                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
@@ -298,7 +302,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
 #define GPMI_SOLVE_ROW(T, NJ, br, X, k)                                                                \
     if ((br) == (k)) {                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) T[GPMI_CL(k, NJ)][i] = s_d16[(k) & 1][lr][lq + 4 * i]; \
-    } else if ((br) > (k)) {                                                                           \
+    } else if ((br) > (k) && GPMI_ACT(br)) {                                                           \
         X = d4{0.0, 0.0, 0.0, 0.0};                                                                    \
         _Pragma("unroll") for (int kg = 0; kg < 4; ++kg)                                               \
             X = mfma(s_inv[k][kg * 64 + lane], T[GPMI_CL(k, NJ)][kg], X);                              \
@@ -327,7 +331,8 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     // packed negative below the diagonal; on the diagonal the factor's tile and the inverse the factor wave left in
     // s_inv[k].  Issued one step later, behind B1, so that the stores do not sit between B2 and B1 (the critical path).
 #define GPMI_STORE_STEP(T, NJ, br, k, PR)                                                              \
-    if ((br) > (k)) {                                                                                  \
+    if ((br) > (k) && !GPMI_ACT(br)) {                                                                 \
+    } else if ((br) > (k)) {                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
             if (FULL || (br) * 16 + lr < nb_act)                                                       \
                 const_cast<double *>(PR)[(size_t)((k) * 16 + 4 * i) * lda] = T[GPMI_CL(k, NJ)][i];     \
@@ -382,12 +387,12 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
             GPMI_STORE_STEP(TB, 5, rb, kb - 1, prb)
             GPMI_STORE_STEP(TC, 2, rc, kb - 1, prc)
             // ... and REST: tiles jb >= kb of the rows below, except tile (kb, kb) (updated EARLY)
-            if (ra >= kb) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
-            if (rb >= kb) { GPMI_UPDATE_REST(TB, 5, rb, XB[kb - 1]) }
-            if (rc >= kb) { GPMI_UPDATE_REST(TC, 2, rc, XC[kb - 1]) }
+            if (ra >= kb && GPMI_ACT(ra)) { GPMI_UPDATE_REST(TA, 8, ra, XA[kb - 1]) }
+            if (rb >= kb && GPMI_ACT(rb)) { GPMI_UPDATE_REST(TB, 5, rb, XB[kb - 1]) }
+            if (rc >= kb && GPMI_ACT(rc)) { GPMI_UPDATE_REST(TC, 2, rc, XC[kb - 1]) }
         }
         GPMI_LDS_BARRIER();  // B2: factor16(kb) done: L16 in s_d16[kb & 1], its inverse in s_inv[kb]
-        if (kb < 7) {     // the critical row kb + 1: solve, EARLY update of the next diagonal tile, hand-over
+        if (kb < 7 && GPMI_ACT(kb + 1)) {     // the critical row kb + 1: solve, EARLY update of the next diagonal tile, hand-over
             if (ra == kb + 1) { GPMI_SOLVE_ROW(TA, 8, ra, XA[kb], kb) GPMI_UPDATE_EARLY(TA, 8, ra, XA[kb]) }
             else if (rb == kb + 1) { GPMI_SOLVE_ROW(TB, 5, rb, XB[kb], kb) GPMI_UPDATE_EARLY(TB, 5, rb, XB[kb]) }
             else if (rc == kb + 1) { GPMI_SOLVE_ROW(TC, 2, rc, XC[kb], kb) GPMI_UPDATE_EARLY(TC, 2, rc, XC[kb]) }
@@ -421,6 +426,7 @@ __device__ __forceinline__ void potrf_diag4_body(double *__restrict__ sm, double
     }
 #endif
 #undef GPMI_CL
+#undef GPMI_ACT
 #undef GPMI_LOAD_TILE
 #undef GPMI_SOLVE_ROW
 #undef GPMI_STORE_STEP

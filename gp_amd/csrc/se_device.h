@@ -101,7 +101,7 @@ __device__ __forceinline__ void se_cov_tile(const double *__restrict__ X, int n,
     // at N = 16384): no bounds, no diagonal, no per-element predicates around the stores.  The build is VALU-bound, not
     // HBM-bound (~80 instructions per element, 30 of them double-precision, against 8 bytes stored), and a quarter of the
     // instructions were exec-mask bookkeeping of the guarded form.
-    if ((vec & 2) && row0 + SE_TR <= n && col0 + SE_TC <= m && (!same || col0 + SE_TC <= row0)) {  // workgroup-uniform
+    if (vec && row0 + SE_TR <= n && col0 + SE_TC <= m && (!same || col0 + SE_TC <= row0)) {  // workgroup-uniform
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int c = col0 + ty * 8 + q;
@@ -116,7 +116,8 @@ __device__ __forceinline__ void se_cov_tile(const double *__restrict__ X, int n,
                 }
             }
             const double v0 = p.a2 * exp_nonpos(-0.5 * s0, ec), v1 = p.a2 * exp_nonpos(-0.5 * s1, ec);
-            store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, true, true, true);
+            if (vec & 2) store_pair<true>(K + (size_t)r + (size_t)c * ldk, v0, v1, true, true, true);
+            else store_pair<false>(K + (size_t)r + (size_t)c * ldk, v0, v1, true, true, true);
         }
         return;
     }
