@@ -2207,6 +2207,17 @@ __device__ __forceinline__ void logml_grad_small_body(double (&smem)[2][2][GK][G
     }
 }
 
+// Completion flag of the one-launch host-buffer calls: the results lie in pinned, device-mapped host memory; every thread
+// makes its stores visible system-wide, the workgroup meets, and thread 0 publishes `seq` -- the host polls the flag instead of
+// paying a stream synchronisation (~8 us of a 30 us call).  done == nullptr: no flag.
+__device__ __forceinline__ void small_signal_done(int *done, int seq)
+{
+    if (!done) return;   // kernel argument: workgroup-uniform
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 constexpr int SMALL_PTS = 128;  // grid points per launch: their hyper-parameters travel as kernel arguments
 struct SmallBatch {
     double a2[SMALL_PTS], inv_rho[SMALL_PTS], diag[SMALL_PTS];
@@ -2232,7 +2243,7 @@ extern __shared__ __attribute__((aligned(16))) double small_lds[];
 __global__ __launch_bounds__(256, 2) void k_logml_small(const double *__restrict__ X, int n, int ldx, const double *__restrict__ y,
                                                      SeParams p, double diag_add, double *__restrict__ W, size_t ld,
                                                      double *__restrict__ out3, int *info_out, int *info_w, ExpC ec,
-                                                     double *__restrict__ stage)
+                                                     double *__restrict__ stage, int *done, int seq)
 {
     GPMI_SMALL_LDS
     if (stage) {
@@ -2252,6 +2263,7 @@ __global__ __launch_bounds__(256, 2) void k_logml_small(const double *__restrict
 #pragma unroll
     for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = p.inv_ell[d];
     logml_small_body(smem, s_F, s_aux, X, n, ldx, y, se, diag_add, W, ld, out3, info_out, info_w, ec);
+    small_signal_done(done, seq);
 }
 
 // workgroup g = point g of the batch: isotropic (alpha, rho, sigma) as in gpmi_logml_grid; workspace slice g
@@ -2319,7 +2331,7 @@ constexpr int SMALL_GRAD_LDS_DOUBLES = SMALL_LDS_DOUBLES + 512;   // s_aux: two 
 __global__ __launch_bounds__(256, 2) void k_logml_grad_small(const double *__restrict__ X, int n, int ldx, const double *__restrict__ y,
                                                           SeParams p, double diag_add, double *__restrict__ W, size_t ld,
                                                           double *__restrict__ U, double *__restrict__ res, int *info_out, int *info_w,
-                                                          ExpC ec, double *__restrict__ stage)
+                                                          ExpC ec, double *__restrict__ stage, int *done, int seq)
 {
     GPMI_SMALL_LDS
     if (stage) {
@@ -2339,6 +2351,7 @@ __global__ __launch_bounds__(256, 2) void k_logml_grad_small(const double *__res
 #pragma unroll
     for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = p.inv_ell[d];
     logml_grad_small_body(smem, s_F, s_aux, X, n, ldx, y, se, diag_add, W, ld, U, res, info_out, info_w, ec);
+    small_signal_done(done, seq);
 }
 
 // ... and G isotropic points (the chains of a sampler: rstan's default is four), one workgroup each; slice g of Wall holds
@@ -2446,7 +2459,7 @@ struct CondArgs {
 __global__ __launch_bounds__(256, 2) void k_gp_condition_small(const double *__restrict__ t, int n, const double *__restrict__ ts, int m,
                                                             const double *__restrict__ y, CondArgs q, double *__restrict__ W, size_t ld,
                                                             double *__restrict__ Kn, size_t ldo, double *__restrict__ mn, int *info_out,
-                                                            int *info_w, double *__restrict__ stage)
+                                                            int *info_w, double *__restrict__ stage, int *done, int seq)
 {
     GPMI_SMALL_LDS
     const int tid = threadIdx.x, nt = n + m;
@@ -2483,6 +2496,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_condition_small(const double *__r
         mn[r] = -W[(size_t)nt + (size_t)(n + r) * ld];
     }
     if (tid == 0) *info_out = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    small_signal_done(done, seq);
 }
 
 // f = chol(cov_exp_quad(X, alpha, ell) + diag_add I) z (models/exact_gp.stan:17-25: the latent exact GP's transform, once per
@@ -2492,7 +2506,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_condition_small(const double *__r
 __global__ __launch_bounds__(256, 2) void k_exact_gp_small(const double *__restrict__ X, int n, int ldx, const double *__restrict__ z,
                                                         SeParams p, double diag_add, double *__restrict__ W, size_t ld,
                                                         double *__restrict__ f, int *info_out, int *info_w, ExpC ec,
-                                                        double *__restrict__ stage)
+                                                        double *__restrict__ stage, int *done, int seq)
 {
     GPMI_SMALL_LDS
     const int tid = threadIdx.x;
@@ -2553,6 +2567,7 @@ __global__ __launch_bounds__(256, 2) void k_exact_gp_small(const double *__restr
         f[i] = info ? __builtin_nan("") : acc;
     }
     if (tid == 0) *info_out = __hip_atomic_load(info_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    small_signal_done(done, seq);
 }
 
 // stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
@@ -3443,11 +3458,11 @@ void small_ws_layout(int n, size_t *ld, size_t *stride)
 }
 
 void launch_logml_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
-                        double *W, size_t ld, double *d_out3, int *d_info_out, int *d_info_work, double *stage)
+                        double *W, size_t ld, double *d_out3, int *d_info_out, int *d_info_work, double *stage, int *done, int seq)
 {
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, dy, p, diag_add, W, ld, d_out3,
-                       d_info_out, d_info_work, h_exp, stage);
+                       d_info_out, d_info_work, h_exp, stage, done, seq);
 }
 
 // G <= GPMI_SMALL_PTS points (alpha, rho, sigma) in ONE launch of G workgroups; Wall: G slices (small_ws_layout)
@@ -3516,13 +3531,13 @@ void launch_logml_small_batch_dev(hipStream_t s, const double *dX, int n, int ld
 
 // value + gradient sums by one workgroup per point: W holds, per point, two slices of small_ws_layout (W, then U)
 void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
-                             double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage)
+                             double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage, int *done, int seq)
 {
     size_t ld, stride;
     small_ws_layout(n, &ld, &stride);
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_grad_small, dim3(1), 256, SMALL_GRAD_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, dy, p, diag_add, W, ld,
-                       W + stride, d_res, d_info_out, d_info_work, h_exp, stage);
+                       W + stride, d_res, d_info_out, d_info_work, h_exp, stage, done, seq);
 }
 
 void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
@@ -3564,24 +3579,24 @@ void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, co
 
 void launch_gp_condition_small(hipStream_t s, const double *t, int n, const double *ts, int m, const double *y, int kindK, int kindS,
                                int kindSS, int compat, double a2, double l2, double s2, double jitter, double *W, double *Kn, size_t ldo,
-                               double *mn, int *info_out, int *d_info_work, double *stage)
+                               double *mn, int *info_out, int *d_info_work, double *stage, int *done, int seq)
 {
     size_t ld, stride;
     small_ws_layout(n + m, &ld, &stride);
     small_lds_attr();
     CondArgs q{kindK, kindS, kindSS, compat, a2, l2, s2, jitter};
     hipLaunchKernelGGL(k_gp_condition_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, t, n, ts, m, y, q, W, ld, Kn, ldo, mn,
-                       info_out, d_info_work, stage);
+                       info_out, d_info_work, stage, done, seq);
 }
 
 void launch_exact_gp_small(hipStream_t s, const double *X, int n, int ldx, const double *z, const SeParams &p, double diag_add,
-                           double *W, double *f, int *info_out, int *d_info_work, double *stage)
+                           double *W, double *f, int *info_out, int *d_info_work, double *stage, int *done, int seq)
 {
     size_t ld, stride;
     small_ws_layout(n, &ld, &stride);
     small_lds_attr();
     hipLaunchKernelGGL(k_exact_gp_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, X, n, ldx, z, p, diag_add, W, ld, f, info_out,
-                       d_info_work, h_exp, stage);
+                       d_info_work, h_exp, stage, done, seq);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

@@ -889,6 +889,7 @@ static void lanes_join(gpmi_ctx *c, int lanes, hipStream_t caller, int la_saved)
 
 // ---- latent exact GP: f = chol(K) z --------------------------------------------------------
 static int pin_reserve(gpmi_ctx *c, size_t need);
+static int pin_wait(gpmi_ctx *c, const int *flag, int seq);
 static int reserve_ws_small(gpmi_ctx *c, int n, int count);
 static int upload_xy(gpmi_ctx *c, const double *X, int n, int ldx, int D, const double *y, double **dX, double **dy);
 extern "C" int gpmi_exact_gp_f(gpmi_ctx *c, const double *X, int n, int ldx, int D, double alpha, const double *ell, int n_ell,
@@ -910,9 +911,10 @@ extern "C" int gpmi_exact_gp_f(gpmi_ctx *c, const double *X, int n, int ldx, int
         if ((rc = scratch_buf(c, (size_t)n * (D + 1) * sizeof(double), &stage))) return rc;
         if ((rc = reserve_ws_small(c, n, 1))) return rc;
         double *pd = c->h_pin_dev;
-        launch_exact_gp_small(s, pd + 8 + n, n, n, pd + 8 + n + (size_t)n * D, p, jitter, c->W, pd + 8, (int *)pd, c->d_info, stage);
+        launch_exact_gp_small(s, pd + 8 + n, n, n, pd + 8 + n + (size_t)n * D, p, jitter, c->W, pd + 8, (int *)pd, c->d_info, stage,
+                              (int *)(pd + 7), ++c->pin_seq);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
+        if ((rc = pin_wait(c, (const int *)(c->h_pin + 7), c->pin_seq))) return rc;
         memcpy(f, hf, (size_t)n * sizeof(double));
         return *(const int *)c->h_pin;
     }
@@ -953,6 +955,19 @@ static int pin_reserve(gpmi_ctx *c, size_t need)
     HIPCHK(hipHostGetDevicePointer((void **)&c->h_pin_dev, c->h_pin, 0));
     c->h_pin_bytes = want;
     return 0;
+}
+
+// wait for the completion flag a one-launch kernel publishes in the pinned buffer (small_signal_done): polling the mapped
+// word costs ~1-2 us after the kernel's last store, a stream synchronisation ~10; the stream is the fallback
+static int pin_wait(gpmi_ctx *c, const int *flag, int seq)
+{
+    for (long it = 0; it < 20000000L; ++it) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+        __builtin_ia32_pause();
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return 0;
+    return gpmi_fail(GPMI_EHIP, "the kernel of a one-launch call did not publish its completion flag");
 }
 
 static bool small_logml(const gpmi_ctx *c, int n, int D, int G = 1)
@@ -1189,10 +1204,11 @@ extern "C" int gpmi_logml(gpmi_ctx *c, const double *X, int n, int ldx, int D, c
         if ((rc = scratch_buf(c, (size_t)n * (D + 1) * sizeof(double), &stage))) return rc;
         if ((rc = reserve_ws_small(c, n, 1))) return rc;
         double *pd = c->h_pin_dev;
+        const int seq = ++c->pin_seq;
         launch_logml_small(c->stream, pd + 8, n, n, pd + 8 + (size_t)n * D, p, sigma * sigma + jitter, c->W, (size_t)c->ld, pd,
-                           (int *)(pd + 3), c->d_info, stage);
+                           (int *)(pd + 3), c->d_info, stage, (int *)(pd + 7), seq);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = pin_wait(c, (const int *)(c->h_pin + 7), seq))) return rc;
         memcpy(out3, c->h_pin, 3 * sizeof(double));
         return *(const int *)(c->h_pin + 3);
     }
@@ -1943,10 +1959,11 @@ extern "C" int gpmi_logml_grad(gpmi_ctx *c, const double *X, int n, int ldx, int
         if ((rc = scratch_buf(c, (size_t)n * (D + 1) * sizeof(double), &stage))) return rc;
         if ((rc = reserve_ws_small(c, n, 2))) return rc;
         double *pd = c->h_pin_dev;
+        const int seq = ++c->pin_seq;
         launch_logml_grad_small(c->stream, pd + 16, n, n, pd + 16 + (size_t)n * D, p, sigma * sigma + jitter, c->W, pd,
-                                (int *)(pd + GPMI_SMALL_GRAD_RES), c->d_info, stage);
+                                (int *)(pd + GPMI_SMALL_GRAD_RES), c->d_info, stage, (int *)(pd + 15), seq);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = pin_wait(c, (const int *)(c->h_pin + 15), seq))) return rc;
         const int info = *(const int *)(c->h_pin + GPMI_SMALL_GRAD_RES);
         for (int k = 0; k < 3; ++k) out3[k] = c->h_pin[k];
         if (info) {
@@ -2088,9 +2105,10 @@ extern "C" int gpmi_gp_condition(gpmi_ctx *c, const double *t, int n, const doub
         double *pd = c->h_pin_dev;
         const size_t o_mn = 8, o_Kn = o_mn + m, o_t = o_Kn + (size_t)m * m, o_ts = o_t + n, o_y = o_ts + m;
         launch_gp_condition_small(c->stream, pd + o_t, n, pd + o_ts, m, pd + o_y, kindK, kindS, kindSS, (flags & GPMI_COMPAT_RR) ? 1 : 0,
-                                  alpha * alpha, l * l, s2, jitter, c->W, pd + o_Kn, (size_t)m, pd + o_mn, (int *)pd, c->d_info, stage);
+                                  alpha * alpha, l * l, s2, jitter, c->W, pd + o_Kn, (size_t)m, pd + o_mn, (int *)pd, c->d_info, stage,
+                                  (int *)(pd + 7), ++c->pin_seq);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((rc = pin_wait(c, (const int *)(c->h_pin + 7), c->pin_seq))) return rc;
         memcpy(mn, hmn, (size_t)m * sizeof(double));
         for (int j = 0; j < m; ++j) memcpy(Kn + (size_t)j * ldkn, hKn + (size_t)j * m, (size_t)m * sizeof(double));
         return *(const int *)c->h_pin;

@@ -68,6 +68,7 @@ struct gpmi_ctx {
     double *d_spar;          // device-parameter small-N grids: GPMI_SMALL_PAR doubles + one work int per point
     int *d_sinfo;
     int spar_pts;            // capacity (points)
+    int pin_seq;             // sequence number of the completion flag in h_pin (one-launch host-buffer calls)
     // generic device staging buffers for the host-pointer API
     double *stage[4];
     size_t stage_bytes[4];
@@ -165,7 +166,8 @@ void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, doub
 void small_ws_layout(int n, size_t *ld, size_t *stride);
 void launch_logml_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
                         double *W, size_t ld, double *d_out3, int *d_info_out, int *d_info_work,
-                        double *stage /* nullable: device staging for host-mapped X, y */);
+                        double *stage /* nullable: device staging for host-mapped X, y */,
+                        int *done = nullptr /* nullable: host-mapped completion flag, set to seq at the end */, int seq = 0);
 void launch_logml_small_batch_ard(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                                   const double *ell /* G x D, point-major */, const double *sigma, int G, double jitter,
                                   double *Wall, double *d_out3, int *d_info_out, int *d_info_work);
@@ -176,7 +178,7 @@ void launch_logml_small_batch(hipStream_t s, const double *dX, int n, int ldx, i
 // sums) by one workgroup per point, n <= 256; the workspace holds TWO slices of small_ws_layout per point (W, then U = L^-T)
 #define GPMI_SMALL_GRAD_RES (3 + 2 + GPMI_MAXD)
 void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
-                             double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage);
+                             double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage, int *done = nullptr, int seq = 0);
 void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                                    const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_res,
                                    int *d_info_out, int *d_info_work);
@@ -188,10 +190,10 @@ void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, co
 // gp_condition by one workgroup (workspace: one slice of small_ws_layout(n + m)); t, ts, y / Kn, mn, info_out may be host-mapped (stage != null)
 void launch_gp_condition_small(hipStream_t s, const double *t, int n, const double *ts, int m, const double *y, int kindK, int kindS,
                                int kindSS, int compat, double a2, double l2, double s2, double jitter, double *W, double *Kn, size_t ldo,
-                               double *mn, int *info_out, int *d_info_work, double *stage);
+                               double *mn, int *info_out, int *d_info_work, double *stage, int *done = nullptr, int seq = 0);
 // f = chol(K + diag_add I) z by one workgroup (n <= 256, D <= GPMI_MAXD); X, z / f, info_out may be host-mapped (stage != null)
 void launch_exact_gp_small(hipStream_t s, const double *X, int n, int ldx, const double *z, const SeParams &p, double diag_add,
-                           double *W, double *f, int *info_out, int *d_info_work, double *stage);
+                           double *W, double *f, int *info_out, int *d_info_work, double *stage, int *done = nullptr, int seq = 0);
 // any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
 #define GPMI_SMALL_PAR (2 + GPMI_MAXD)
 #define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS
