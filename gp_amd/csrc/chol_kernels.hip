@@ -2359,10 +2359,23 @@ __global__ __launch_bounds__(256, 2) void k_logml_grad_small(const double *__res
 __global__ __launch_bounds__(256, 2) void k_logml_grad_small_batch(const double *__restrict__ X, int n, int ldx, int D,
                                                                 const double *__restrict__ y, SmallBatch b,
                                                                 double *__restrict__ Wall, size_t wstride, size_t ustride, size_t ld,
-                                                                double *__restrict__ res, int *info_out, int *info_w, ExpC ec)
+                                                                double *__restrict__ res, int *info_out, int *info_w, ExpC ec,
+                                                                double *__restrict__ stage, int *done, int seq, int *arrive)
 {
     GPMI_SMALL_LDS
     const int g = blockIdx.x;
+    if (stage) {   // X, y host-mapped (few chains: every workgroup stages its own copy, one PCIe round trip, side by side)
+        double *st = stage + (size_t)g * n * (D + 1);
+        const int nx = n * D;
+        for (int e = threadIdx.x; e < nx + n; e += 256) {
+            const int d = e / n, i = e - d * n;
+            st[e] = (e < nx) ? X[(size_t)i + (size_t)d * ldx] : y[e - nx];
+        }
+        __syncthreads();
+        X = st;
+        y = st + nx;
+        ldx = n;
+    }
     SmallSe se;
     se.a2 = b.a2[g];
     se.D = D;
@@ -2371,6 +2384,17 @@ __global__ __launch_bounds__(256, 2) void k_logml_grad_small_batch(const double 
     double *W = Wall + (size_t)g * wstride;
     logml_grad_small_body(smem, s_F, s_aux, X, n, ldx, y, se, b.diag[g], W, ld, W + ustride, res + (size_t)g * SMALL_GRAD_RES,
                           info_out + g, info_w + g, ec);
+    if (done) {   // the LAST workgroup to finish publishes the completion flag (device counter `arrive`, re-armed by it)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int k = __hip_atomic_fetch_add(arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == (int)gridDim.x - 1) {
+                __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // One posterior draw of the derivative process (sample_derivs, pendulum_fit.R:227-255) per workgroup: the loop
@@ -3542,7 +3566,7 @@ void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, co
 
 void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                                    const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_res,
-                                   int *d_info_out, int *d_info_work)
+                                   int *d_info_out, int *d_info_work, double *stage, int *done, int seq, int *arrive)
 {
     SmallBatch b;
     for (int g = 0; g < G; ++g) {
@@ -3554,7 +3578,7 @@ void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int l
     small_ws_layout(n, &ld, &stride);
     small_lds_attr();
     hipLaunchKernelGGL(k_logml_grad_small_batch, dim3(G), 256, SMALL_GRAD_LDS_DOUBLES * sizeof(double), s, dX, n, ldx, D, dy, b, Wall,
-                       2 * stride, stride, ld, d_res, d_info_out, d_info_work, h_exp);
+                       2 * stride, stride, ld, d_res, d_info_out, d_info_work, h_exp, stage, done, seq, arrive);
 }
 
 // B draws by one workgroup each; Wall: B slices of small_ws_layout(n + m); dY: n x B, dZ, draws, mus: m x B (packed); d_par: 3 B

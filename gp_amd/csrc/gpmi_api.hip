@@ -2010,6 +2010,37 @@ extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx
     std::vector<SeParams> ps(G);
     for (int g = 0; g < G; ++g)
         if ((rc = fill_params(&ps[g], D, alpha[g], &rho[g], 1))) return rc;
+    if (D <= GPMI_MAXD && n <= (G >= 2 ? c->tune.small_ng : c->tune.small_ng1) && G <= 8) {
+        // a sampler's handful of chains: ONE launch, X, y in and the results out through the pinned, device-mapped buffer
+        // (no copy call, no stream synchronisation): [res (G x 13) | info (G ints) | flag | X | y]
+        const size_t o_info = (size_t)G * GPMI_SMALL_GRAD_RES, o_flag = o_info + (G + 1) / 2, o_x = o_flag + 1;
+        const size_t need = (o_x + (size_t)n * (D + 1)) * sizeof(double);
+        if ((rc = pin_reserve(c, need))) return rc;
+        double *hX = c->h_pin + o_x, *hy = hX + (size_t)n * D, *stage;
+        for (int d = 0; d < D; ++d) memcpy(hX + (size_t)d * n, X + (size_t)d * ldx, (size_t)n * sizeof(double));
+        memcpy(hy, y, (size_t)n * sizeof(double));
+        if ((rc = scratch_buf(c, (size_t)G * n * (D + 1) * sizeof(double), &stage))) return rc;
+        if ((rc = reserve_ws_small(c, n, 2 * G))) return rc;
+        if ((rc = reserve_small_par(c, G))) return rc;
+        double *pd = c->h_pin_dev;
+        const int seq = ++c->pin_seq;
+        launch_logml_grad_small_batch(c->stream, pd + o_x, n, n, D, pd + o_x + (size_t)n * D, alpha, rho, sigma, G, jitter, c->W, pd,
+                                      (int *)(pd + o_info), c->d_sinfo, stage, (int *)(pd + o_flag), seq, c->d_ctr + 40);
+        HIPCHK(hipGetLastError());
+        if ((rc = pin_wait(c, (const int *)(c->h_pin + o_flag), seq))) return rc;
+        const int *hinfo = (const int *)(c->h_pin + o_info);
+        for (int g = 0; g < G; ++g) {
+            const double *r = c->h_pin + (size_t)g * GPMI_SMALL_GRAD_RES;
+            info[g] = hinfo[g];
+            for (int k = 0; k < 3; ++k) out3[3 * g + k] = r[k];
+            if (info[g]) {
+                for (int k = 0; k < 3; ++k) grad[3 * g + k] = NAN;
+            } else {
+                logml_grad_finish(r + 3, D, alpha[g], &rho[g], 1, sigma[g], grad + 3 * g);
+            }
+        }
+        return 0;
+    }
     if (D <= GPMI_MAXD && n <= (G >= 2 ? c->tune.small_ng : c->tune.small_ng1)) {
         // one workgroup per point, up to GPMI_SMALL_PTS points per launch (parameters as kernel arguments)
         double *dX, *dy, *dres;

@@ -181,7 +181,8 @@ void launch_logml_grad_small(hipStream_t s, const double *dX, int n, int ldx, co
                              double *W, double *d_res, int *d_info_out, int *d_info_work, double *stage, int *done = nullptr, int seq = 0);
 void launch_logml_grad_small_batch(hipStream_t s, const double *dX, int n, int ldx, int D, const double *dy, const double *alpha,
                                    const double *rho, const double *sigma, int G, double jitter, double *Wall, double *d_res,
-                                   int *d_info_out, int *d_info_work);
+                                   int *d_info_out, int *d_info_work, double *stage = nullptr /* G n (D + 1) doubles: X, y host-mapped */,
+                                   int *done = nullptr, int seq = 0, int *arrive = nullptr /* zeroed device int, left zero */);
 // B posterior draws of the derivative process, one workgroup each (workspace: B slices of small_ws_layout(n + m); d_par: 3 B doubles,
 // d_info_work: 2 B ints)
 void launch_sample_derivs_small_batch(hipStream_t s, const double *dt, int n, const double *dts, int m, const double *dY,
