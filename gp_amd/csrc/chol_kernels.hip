@@ -2947,6 +2947,8 @@ void gpmi_tuning_defaults(gpmi_tuning *t)
     t->small_ng1 = 128;   // tools/grad_small_bench.py: one workgroup 57 / 82 / 109 / 207 / 303 / 337 us at n = 21 / 64 / 128 / 160 / 199 / 256,
                           // the launch chain 151 / 162 / 180 / ~225 / 274 / 272; four chains at once 93 .. 363 us against 377 .. 525
     t->small_ng = 256;
+    t->grad_aug_n = 3072;
+    t->grad_aug_ng = 2304;
     t->small_gc = 180;    // gpmi_gp_condition by one workgroup up to n + m + 1 rows (tools/cond_bench.py)
     t->small_sd = 640;
     t->small_sdb = 5;     // tools/sample_derivs_bench.py: one workgroup 0.21 / 0.56 / 0.73 ms at n = m = 79 / 199 / 256, the lanes 95 / 136 / 129 us per draw

@@ -411,6 +411,11 @@ extern "C" int gpmi_set_option(gpmi_ctx *c, const char *name, int value)
         (name[8] == '1' ? c->tune.small_ng1 : c->tune.small_ng) = value;
         return 0;
     }
+    if (!strcmp(name, "grad_aug_n") || !strcmp(name, "grad_aug_ng")) {  // value + gradient through ONE augmented partial factorisation
+        if (value < 0) return gpmi_fail(GPMI_EARG, "%s must be >= 0", name);   // up to this n: one evaluation / several at once (0: off)
+        (name[10] == 'g' ? c->tune.grad_aug_ng : c->tune.grad_aug_n) = value;
+        return 0;
+    }
     if (!strcmp(name, "small_gc")) {  // gp_condition by one workgroup up to this many rows n + m + 1 (0: off)
         if (value < 0 || value > 1024) return gpmi_fail(GPMI_EARG, "small_gc must be 0 .. 1024");
         c->tune.small_gc = value;
@@ -1868,11 +1873,46 @@ __global__ __launch_bounds__(1024) void k_grad_final(const double *__restrict__ 
 }
 }  // namespace
 
+// Mid sizes (n <= tune.grad_aug_n): K^-1 and a = K^-1 y from ONE augmented partial factorisation instead of a second and a
+// third launch chain (L^-T from the identity, then U U^T).  The workspace holds the (2n + 1)-row matrix
+//     [ K        .   ]   n rows          after factoring the first n columns (launch_potrf_partial, the kernel chain of
+//     [ y^T      0   ]   1 row           gpmi_gp_condition) the rows below are [z^T; U], U = I L^-T = L^-T, and the
+//     [ I        0   ]   n rows          trailing block is 0 - [z^T; U][z^T; U]^T = -[[z'z, a^T], [a, K^-1]],  a = U z.
+// The triangular structure of I and U is not exploited (2.3 n^3 flops instead of n^3) -- at these sizes the evaluation is a
+// latency chain of ~36 us per 128-column panel, and this form has ONE chain where the other has three.
+namespace {
+__global__ void k_aug_identity(double *__restrict__ A, size_t ld, int n)   // A: rows n + 1 .. 2n of columns 0 .. n - 1
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= n) return;
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j < n) A[(size_t)i + (size_t)j * ld] = (i == j) ? 1.0 : 0.0;
+    }
+}
+}  // namespace
+
+// many: several evaluations share the chip (the lanes): flops count for more, the limit is lower
+// (tools/grad_aug_bench.py, us: n = 1438 603 vs 1128 alone, 1216 vs 1980 for four chains; 2048: 979 vs 1482, 2155 vs 2720;
+// 2560: 1470 vs 1824, 3636 vs 3497; 3072: 2152 vs 2276, 5550 vs 4566; 3584: 2953 vs 2797)
+static bool grad_augmented(const gpmi_ctx *c, int n, bool many)
+{
+    const int lim = many ? c->tune.grad_aug_ng : c->tune.grad_aug_n;
+    return lim > 0 && n <= lim;
+}
+
 // every buffer logml_grad_core(c, ., n, ...) uses, at its final size
-static int logml_grad_reserve(gpmi_ctx *c, int n, int D)
+static int logml_grad_reserve(gpmi_ctx *c, int n, int D, bool many = false)
 {
     const int ns = grad_ns(D);
     int rc;
+    if (grad_augmented(c, n, many)) {
+        if ((rc = reserve_ws(c, 2 * n + 1, 2 * n + 1))) return rc;
+        const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
+        double *b;
+        return stage_buf(c, 3, ((size_t)GRAD_NS_MAX + ntiles * ns) * sizeof(double), &b);
+    }
     if ((rc = reserve_ws(c, n + 1, n))) return rc;
     const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
     const int npan = (n + GPMI_NB - 1) / GPMI_NB;
@@ -1888,11 +1928,35 @@ static int logml_grad_reserve(gpmi_ctx *c, int n, int D)
 // d_res[0..2] = (logml, sum log L_ii, z'z), d_res[3 .. 3 + grad_ns(D)) = the contraction sums, *d_info = status
 constexpr int GRAD_RES = 3 + GRAD_NS_MAX;
 static int logml_grad_core(gpmi_ctx *c, const double *dX, int n, int ldx, const double *dy, const SeParams &p, double diag_add,
-                           double *d_res, int *d_info)
+                           double *d_res, int *d_info, bool many = false)
 {
     int rc;
-    if ((rc = logml_grad_reserve(c, n, p.D))) return rc;
+    if ((rc = logml_grad_reserve(c, n, p.D, many))) return rc;
     const int ns = grad_ns(p.D);
+    if (grad_augmented(c, n, many)) {
+        const int M2 = 2 * n + 1;
+        const size_t ld = (size_t)c->ld;
+        const size_t T = (size_t)((n + 63) / 64), ntiles = T * (T + 1) / 2;
+        double *sums = c->stage[3], *part = sums + GRAD_NS_MAX;
+        hipStream_t s = c->stream;
+        HIPCHK(hipMemsetAsync(c->d_info, 0, sizeof(int), s));
+        launch_se_cov(c, s, dX, n, ldx, nullptr, n, ldx, p, diag_add, 1, c->W, ld);
+        launch_set_row(s, c->W, ld, n, dy, n, n);
+        hipLaunchKernelGGL(k_aug_identity, dim3((n + 63) / 64, (n + 15) / 16), 256, 0, s, c->W + n + 1, ld, n);
+        HIPCHK(hipMemsetAsync(c->W + (size_t)n * ld, 0, ld * (size_t)(n + 1) * sizeof(double), s));   // columns n .. 2n
+        if ((rc = launch_potrf_partial(c, c->W, ld, M2, M2, n, c->d_info, nullptr))) return rc;
+        launch_logml_finalize(s, c->W, ld, n, n, c->d_info, d_res, d_info, c->d_fin);
+        // trailing block at (n, n): [[-z'z, .], [-a, -K^-1]]; the products a_i a_j do not see a's sign
+        const double *av = c->W + (size_t)(n + 1) + (size_t)n * ld;
+        const double *Wk = c->W + (size_t)(n + 1) + (size_t)(n + 1) * ld;
+        if (p.D <= GPMI_MAXD)
+            hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, ldx, p, av, Wk, ld, part);
+        else
+            hipLaunchKernelGGL(k_grad_partial_big, dim3((unsigned)T, (unsigned)T), 256, 0, s, dX, n, ldx, p, av, Wk, ld, part, ns);
+        hipLaunchKernelGGL(k_grad_final, dim3(1), 1024, 0, s, part, ntiles, d_res + 3, ns);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const int M = n + 1;
     const size_t ld = (size_t)c->ld;
     const size_t ldu = (size_t)(((n + 15) / 16) * 16 + 16);
@@ -2076,7 +2140,7 @@ extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx
     if (lanes > G) lanes = G;
     if ((rc = lanes_prepare(c, lanes))) return rc;
     for (int k = 0; k < lanes; ++k)
-        if ((rc = logml_grad_reserve(k ? c->lane[k - 1] : c, n, D))) return rc;
+        if ((rc = logml_grad_reserve(k ? c->lane[k - 1] : c, n, D, G > 1))) return rc;
     double *dX, *dy, *dres;
     if ((rc = upload_xy(c, X, n, ldx, D, y, &dX, &dy))) return rc;
     // the root context's scratch also holds its packed panel factors (logml_grad_reserve): the results live behind them
@@ -2089,7 +2153,7 @@ extern "C" int gpmi_logml_grad_grid(gpmi_ctx *c, const double *X, int n, int ldx
     lanes_fork(c, lanes, caller);
     for (int g = 0; g < G && !rc; ++g) {
         gpmi_ctx *lc = (g % lanes == 0) ? c : c->lane[g % lanes - 1];
-        rc = logml_grad_core(lc, dX, n, n, dy, ps[g], sigma[g] * sigma[g] + jitter, dres + (size_t)g * GRAD_RES, dinfo + g);
+        rc = logml_grad_core(lc, dX, n, n, dy, ps[g], sigma[g] * sigma[g] + jitter, dres + (size_t)g * GRAD_RES, dinfo + g, G > 1);
     }
     lanes_join(c, lanes, caller, la_saved);
     if (rc) return rc;

@@ -37,6 +37,7 @@ struct gpmi_tuning {
     int small_n1;         // ... a single evaluation (or a grid of fewer than 6 points) up to this n: beyond it the multi-CU launch chain is faster
     int small_m;          // partial factorisation of <= small_m rows: one workgroup, one launch (0: off)
     int small_ng1, small_ng; // value + gradient by one workgroup: one evaluation up to n <= small_ng1, several (a sampler's chains) up to small_ng (<= 256; 0: off)
+    int grad_aug_n, grad_aug_ng;  // gpmi_logml_grad / _grid: K^-1 and K^-1 y from one augmented partial factorisation up to this n (0: off)
     int small_gc;            // gpmi_gp_condition: one workgroup, one launch, up to n + m + 1 <= small_gc rows (0: off)
     int small_sd, small_sdb; // sample_derivs_batch: one workgroup per draw when n + m + 1 <= small_sd rows and at least small_sdb (n + m + 1)^2 / 400^2 draws (0: off)
     int small_n2, small_g2;  // grids of >= small_g2 (n / 1024)^2 + 2 points: one workgroup per point up to n <= small_n2 (every CU a problem of its own)

@@ -87,7 +87,8 @@ GPMI_API int gpmi_reserve(gpmi_ctx *ctx, int n_max);
  * of 128, 0 = auto), "grid_lanes", "fuse_diag", "ksplit", "block_recursive", "stagger", "se_nt", "nb_adapt",
  * "nb_thr1024", "nb_thr512", "nb_thr256", "small_n", "small_n1", "small_m" (one-workgroup kernels for small
  * problems), "small_ng1", "small_ng" (value + gradient by one workgroup: one evaluation up to n <= small_ng1, several at once
- * up to n <= small_ng <= 256), "small_gc" (gpmi_gp_condition in one launch up to n + m + 1 <= small_gc rows), "small_sd", "small_sdb" (gpmi_sample_derivs[_batch]: one workgroup per draw up to
+ * up to n <= small_ng <= 256), "grad_aug_n", "grad_aug_ng" (value + gradient through ONE augmented partial factorisation up
+ * to this n: one evaluation / several at once), "small_gc" (gpmi_gp_condition in one launch up to n + m + 1 <= small_gc rows), "small_sd", "small_sdb" (gpmi_sample_derivs[_batch]: one workgroup per draw up to
  * n + m + 1 <= small_sd rows for at least small_sdb ((n + m + 1) / 400)^2 draws), "small_n2", "small_g2" (grids of at least small_g2 (n / 1024)^2 + 2 points run one workgroup per point up
  * to n <= small_n2 <= 1024), "calibrate", "timing", "kernel_timing"; unknown names return GPMI_EARG.  Switches of variants that
  * were measured and rejected ("lookahead", "syrk_order", "diag_waves", "gemm_variant", ...) exist in the probe

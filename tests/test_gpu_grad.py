@@ -18,7 +18,11 @@ def test_grad_vs_oracle(ctx, orc, n, D):
     want_out, want_g, info = orc.logml_grad(X, y, a, r, s)
     assert info == 0
     assert abs(out[0] - want_out[0]) <= 1e-9 * abs(want_out[0])
-    assert out[0] == ctx.logml(X, y, a, [r], s)[0]  # same factorisation as the plain entry point (one workgroup up to n = 128, the launch chain beyond)
+    plain = ctx.logml(X, y, a, [r], s)[0]
+    if n <= 128:
+        assert out[0] == plain      # the same one-workgroup factorisation as the plain entry point
+    else:                           # mid sizes: the augmented (2n + 1)-row factorisation picks other block widths: to rounding
+        assert abs(out[0] - plain) <= 1e-12 * abs(plain)
     np.testing.assert_allclose(g, want_g, rtol=1e-8, atol=1e-8 * np.abs(want_g).max())
 
 
@@ -187,3 +191,28 @@ def test_small_gradient_chains_in_one_launch(ctx, orc):
     o1, g1 = ctx.logml_grad(X, yy, a[5], [r[5]], s[5])   # default: the launch chain at n = 199 -- same numbers to rounding
     assert abs(out[5, 0] - o1[0]) <= 1e-12 * abs(o1[0])
     np.testing.assert_allclose(g[5], g1, rtol=1e-9, atol=1e-9 * np.abs(g1).max())
+
+
+@pytest.mark.parametrize("n,D", [(257, 1), (1000, 3), (1438, 1), (2500, 2)])
+def test_mid_size_gradient_from_one_augmented_factorisation(ctx, orc, n, D):
+    """128 < n <= 3072: K^-1 and K^-1 y come out of ONE partial factorisation of the (2n + 1)-row matrix [[K], [y'], [I]]
+    (trailing block = -[[z'z, a'], [a, K^-1]]) instead of two more launch chains (N = 1438, the reference's westbrook.R size:
+    1146 -> 606 us): against the three-chain form (grad_aug_n = 0) and, at the smaller sizes, the oracle."""
+    X, y = orc.synth(n, D, seed=n)
+    a, r, s = 1.1, 0.35 * math.sqrt(D), 0.12
+    out, g = ctx.logml_grad(X, y, a, [r], s)
+    ctx.set_option("grad_aug_n", 0)
+    try:
+        out3, g3 = ctx.logml_grad(X, y, a, [r], s)
+    finally:
+        ctx.set_option("grad_aug_n", 3072)
+    assert abs(out[0] - out3[0]) <= 1e-12 * abs(out3[0])
+    np.testing.assert_allclose(g, g3, rtol=1e-8, atol=1e-8 * np.abs(g3).max())
+    if n <= 1000:
+        wo, wg, info = orc.logml_grad(X, y, a, r, s)
+        assert info == 0
+        np.testing.assert_allclose(g, wg, rtol=1e-8, atol=1e-8 * np.abs(wg).max())
+    from gp_amd import NotPositiveDefinite
+    if n == 257:
+        with pytest.raises(NotPositiveDefinite):
+            ctx.logml_grad(np.zeros((n, 1)), np.ones(n), 1.0, [0.5], 0.0)
