@@ -2594,6 +2594,116 @@ __global__ __launch_bounds__(256, 2) void k_exact_gp_small(const double *__restr
     small_signal_done(done, seq);
 }
 
+// rbf_cov_chol (covariance.cpp:9-47) by ONE workgroup for n <= 128 (test_interpolate.R:5 runs it at N = 100, P = 10 times):
+// Sigma_ij = exp(-(x_i - x_j)^2 / (2 l^2)) + 1e-10 [i == j], L = chol(Sigma), and the forward-mode tangent
+// dL/dl = L Phi(L^-1 Sdot L^-T), Sdot_ij = Sigma_ij (x_i - x_j)^2 / l^3, Phi = lower triangle with halved diagonal --
+// the launch chain of rbf_cov_chol_core (build, factor, copy, tangent build, two panel solves, two transposes, mask, product:
+// ~12 launches) with the same device functions back to back.  Workgroup g handles length-scale ls[g] and writes L (upper
+// zeroed) and dL/dl (lower; its upper triangle exact zeros) to Lout + g ostride, dLout + g ostride (leading dimension ldo;
+// device or host-mapped memory).  Workspace per workgroup: three slices of small_ws_layout(n) (Sigma / L, S, S2).
+struct RbfBatch {
+    double l[64];
+};
+__global__ __launch_bounds__(256, 2) void k_rbf_cov_chol_small(const double *__restrict__ x, int n, RbfBatch ls, double *__restrict__ Wall,
+                                                            size_t wstride, size_t ld, double *__restrict__ Lout,
+                                                            double *__restrict__ dLout, size_t ostride, size_t ldo, int *info_out,
+                                                            int *info_w, ExpC ec, double *__restrict__ stage)
+{
+    GPMI_SMALL_LDS
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const double l = ls.l[g];
+    double *W = Wall + (size_t)g * 3 * wstride, *S = W + wstride, *S2 = S + wstride;
+    double *Lo = Lout + (size_t)g * ostride, *dLo = dLout + (size_t)g * ostride;
+    int *iw = info_w + g;
+    if (stage) {   // x host-mapped: one copy per workgroup
+        double *st = stage + (size_t)g * n;
+        for (int i = tid; i < n; i += 256) st[i] = x[i];
+        __syncthreads();
+        x = st;
+    }
+    if (tid == 0) *iw = 0;
+    SmallSe se;
+    se.a2 = 1.0;
+    se.D = 1;
+#pragma unroll
+    for (int d = 0; d < GPMI_MAXD; ++d) se.inv_ell[d] = 1.0 / l;
+    double *xs = &smem[0][0][0][0];
+    for (int i = tid; i < n; i += 256) xs[i] = __dmul_rn(x[i], se.inv_ell[0]);
+    __syncthreads();
+    for (int row0 = 0; row0 < n; row0 += SE_TR)
+        for (int col0 = 0; col0 < row0 + SE_TR && col0 < n; col0 += SE_TC)
+            se_cov_tile<1, true>(xs, n, n, xs, n, n, se, 1e-10, 1, 1, W, ld, 1, ec, row0, col0);
+    // Sdot, full (the arithmetic of k_rbf_dsigma), thread = row
+    for (int i = tid; i < n; i += 256) {
+        const double xi = x[i];
+        for (int j = 0; j < n; ++j) {
+            const double r = xi - x[j], r2 = r * r;
+            S[(size_t)i + (size_t)j * ld] = exp(-r2 / (2 * l * l)) * r2 / (l * l * l);
+        }
+    }
+    __syncthreads();
+    const int nblk = (n + 15) >> 4;
+    if (n == GPMI_NB) potrf_diag4_body<false, true>(&smem[0][0][0][0], W, ld, n, s_F, iw, 0, 8, tid);
+    else potrf_diag4_body<false, false>(&smem[0][0][0][0], W, ld, n, s_F, iw, 0, nblk, tid);
+    __syncthreads();
+    // (the element-wise passes below keep eight loads in flight per round trip: a loop with one dependent load per iteration
+    // is a chain of n memory latencies -- 100 us per pass at n = 100)
+    // L out, and its upper triangle zeroed in place: W is the A operand of the last product
+    for (int i = tid; i < n; i += 256)
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q < n ? j0 + q : n - 1;
+                v[q] = W[(size_t)i + (size_t)j * ld];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q;
+                if (j < n) {
+                    if (j > i) W[(size_t)i + (size_t)j * ld] = 0.0;
+                    Lo[(size_t)i + (size_t)j * ldo] = (j <= i) ? v[q] : 0.0;
+                }
+            }
+        }
+    auto solve_rows = [&](double *A) {   // A <- A L^-T, all n rows, 64 per round
+        for (int rb = 0; rb < n; rb += 64) {
+            const int r = rb + (tid >> 6) * 16 + (tid & 15);
+            if (n == GPMI_NB && rb + 64 <= n) trsm_panel_body<true>(s_F, A, ld, r, true, n, tid);
+            else trsm_panel_body<false>(s_F, A, ld, r, r < n, n, tid);
+        }
+        __syncthreads();
+    };
+    solve_rows(S);                                                  // S = Sdot L^-T
+    for (int i = tid; i < n; i += 256)                              // S2 = S^T = L^-1 Sdot
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = S[(size_t)(j0 + q < n ? j0 + q : n - 1) + (size_t)i * ld];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + q < n) S2[(size_t)i + (size_t)(j0 + q) * ld] = v[q];
+        }
+    __syncthreads();
+    solve_rows(S2);                                                 // S2 = M = L^-1 Sdot L^-T
+    // B operand of the product: row j, column k holds Phi(M)[k][j]  (k >= j; the diagonal halved)
+    for (int j = tid; j < n; j += 256)
+        for (int k0 = 0; k0 < n; k0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = S2[(size_t)(k0 + q < n ? k0 + q : n - 1) + (size_t)j * ld];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q;
+                if (k < n) S[(size_t)j + (size_t)k * ld] = (k > j) ? v[q] : ((k == j) ? 0.5 * v[q] : 0.0);
+            }
+        }
+    __syncthreads();
+    gemm_tile<2>(smem, W, ld, S, ld, dLo, ldo, n, n, n, 0, 0, 0, tid);   // dL = L Phi (n <= 128: one tile)
+    __syncthreads();
+    if (tid == 0) info_out[g] = __hip_atomic_load(iw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // stream-ordered upload of up to PUT_MAX doubles that travel as kernel arguments (no staging buffer whose reuse would
 // have to be fenced against an earlier asynchronous call)
 constexpr int PUT_MAX = 480;
@@ -2918,6 +3028,7 @@ static void small_lds_attr()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sample_derivs_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gp_condition_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_exact_gp_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rbf_cov_chol_small), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     const int gbytes = SMALL_GRAD_LDS_DOUBLES * (int)sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_logml_grad_small_batch), hipFuncAttributeMaxDynamicSharedMemorySize, gbytes);
@@ -3623,6 +3734,19 @@ void launch_exact_gp_small(hipStream_t s, const double *X, int n, int ldx, const
     small_lds_attr();
     hipLaunchKernelGGL(k_exact_gp_small, dim3(1), 256, SMALL_LDS_DOUBLES * sizeof(double), s, X, n, ldx, z, p, diag_add, W, ld, f, info_out,
                        d_info_work, h_exp, stage, done, seq);
+}
+
+// P <= 64 length-scales, one workgroup each (n <= 128); Wall: 3 P slices of small_ws_layout(n)
+void launch_rbf_cov_chol_small(hipStream_t s, const double *x, int n, const double *ls, int P, double *Wall, double *Lout, double *dLout,
+                               size_t ostride, size_t ldo, int *info_out, int *d_info_work, double *stage)
+{
+    RbfBatch b;
+    for (int p = 0; p < P; ++p) b.l[p] = ls[p];
+    size_t ld, stride;
+    small_ws_layout(n, &ld, &stride);
+    small_lds_attr();
+    hipLaunchKernelGGL(k_rbf_cov_chol_small, dim3(P), 256, SMALL_LDS_DOUBLES * sizeof(double), s, x, n, b, Wall, stride, ld, Lout, dLout,
+                       ostride, ldo, info_out, d_info_work, h_exp, stage);
 }
 
 void launch_pack_factors(hipStream_t s, const double *L, size_t ldl, int n, double *Fpack_all)

@@ -1432,8 +1432,28 @@ extern "C" int gpmi_rbf_cov_chol(gpmi_ctx *c, const double *x, int n, double l, 
     if (n <= 0 || !x || !L || !dLdl || ldl < n || lddl < n || !(l > 0.0)) return gpmi_fail(GPMI_EARG, "bad argument");
     int rc, ldd;
     double *dx, *Lc, *S;
-    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
     hipStream_t s = c->stream;
+    if (n <= 64) {
+        // small n: ONE launch of one workgroup; x in, L / dL/dl / info out through the pinned, device-mapped buffer:
+        // [info | x | L (n x n) | dLdl (n x n)]  (tools/interp_small_bench.py: n = 50 144 -> 84 us; at n = 100 one workgroup
+        // takes 170 us against the chain's 157 -- ONE call stays on the chain there, the table build below does not)
+        const size_t o_x = 8, o_L = o_x + n, o_dL = o_L + (size_t)n * n;
+        if ((rc = pin_reserve(c, (o_dL + (size_t)n * n) * sizeof(double)))) return rc;
+        memcpy(c->h_pin + o_x, x, (size_t)n * sizeof(double));
+        double *stage;
+        if ((rc = scratch_buf(c, (size_t)n * sizeof(double), &stage))) return rc;
+        if ((rc = reserve_ws_small(c, n, 3))) return rc;
+        double *pd = c->h_pin_dev;
+        launch_rbf_cov_chol_small(s, pd + o_x, n, &l, 1, c->W, pd + o_L, pd + o_dL, 0, (size_t)n, (int *)pd, c->d_info, stage);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        for (int j = 0; j < n; ++j) {
+            memcpy(L + (size_t)j * ldl, c->h_pin + o_L + (size_t)j * n, (size_t)n * sizeof(double));
+            memcpy(dLdl + (size_t)j * lddl, c->h_pin + o_dL + (size_t)j * n, (size_t)n * sizeof(double));
+        }
+        return *(const int *)c->h_pin;
+    }
+    if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double), &dx))) return rc;
     HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = rbf_cov_chol_core(c, dx, n, l, &Lc, &S, &ldd))) return rc;
     int info = 0;
@@ -1494,6 +1514,28 @@ extern "C" int gpmi_interp_build(gpmi_ctx *c, const double *x, int n, const doub
     int *dinfo;
     if ((rc = stage_buf(c, 0, (size_t)n * sizeof(double) + (size_t)P * sizeof(int) + 64, &dx))) return rc;
     dinfo = (int *)(dx + n + 1);
+    if (n <= GPMI_NB) {
+        // the reference's size (N = 100, P = 10): the whole table in launches of up to 64 workgroups, one entry each, written
+        // straight into the table
+        hipStream_t s = c->stream;
+        HIPCHK(hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        const int per = P < 64 ? P : 64;
+        if ((rc = reserve_ws_small(c, n, 3 * per))) return rc;
+        if ((rc = reserve_small_par(c, per))) return rc;
+        const size_t msz = c->itp_ld * (size_t)n;
+        for (int p0 = 0; p0 < P; p0 += per) {
+            const int pc = (P - p0 < per) ? P - p0 : per;
+            launch_rbf_cov_chol_small(s, dx, n, lp + p0, pc, c->W, c->itp_L + (size_t)p0 * msz, c->itp_dL + (size_t)p0 * msz, msz,
+                                      c->itp_ld, dinfo + p0, c->d_sinfo, nullptr);
+        }
+        std::vector<int> info(P, 0);
+        HIPCHK(hipMemcpyAsync(info.data(), dinfo, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        for (int p = 0; p < P; ++p)
+            if (info[p]) return info[p];
+        return 0;
+    }
     // The P table entries (test_interpolate.R:9-19: P calls of rbf_cov_chol; interpolated_gp.stan:10-28)
     // are independent factorisations: they run on the grid lanes, entry p on lane p mod lanes, every
     // lane in its own workspace and staging buffers, and nothing synchronises with the host until

@@ -196,6 +196,10 @@ void launch_gp_condition_small(hipStream_t s, const double *t, int n, const doub
 // f = chol(K + diag_add I) z by one workgroup (n <= 256, D <= GPMI_MAXD); X, z / f, info_out may be host-mapped (stage != null)
 void launch_exact_gp_small(hipStream_t s, const double *X, int n, int ldx, const double *z, const SeParams &p, double diag_add,
                            double *W, double *f, int *info_out, int *d_info_work, double *stage, int *done = nullptr, int seq = 0);
+// rbf_cov_chol (L and dL/dl) for P <= 64 length-scales, one workgroup each, n <= 128 (workspace: 3 P slices of small_ws_layout(n));
+// x / Lout, dLout, info_out may be host-mapped (stage != null: P n doubles of device scratch)
+void launch_rbf_cov_chol_small(hipStream_t s, const double *x, int n, const double *ls, int P, double *Wall, double *Lout, double *dLout,
+                               size_t ostride, size_t ldo, int *info_out, int *d_info_work, double *stage);
 // any number of points, parameters uploaded to d_par (G * GPMI_SMALL_PAR doubles) in stream order; ell: one per point (n_ell == 1) or D per point
 #define GPMI_SMALL_PAR (2 + GPMI_MAXD)
 #define GPMI_SMALL_NMAX 1024   // n * D <= 9216: the scaled coordinates are staged in the workgroup's LDS

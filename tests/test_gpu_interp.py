@@ -162,3 +162,28 @@ def test_table_built_on_lanes_equals_single_factorisations(ctx, orc):
     with pytest.raises(gp_amd.NotPositiveDefinite):
         ctx.interp_build(xb, [0.5, 0.8, 0.9])
     ctx.interp_free()
+
+
+@pytest.mark.parametrize("n,P", [(5, 3), (50, 10), (100, 10), (128, 70)])
+def test_small_table_build_in_one_launch(ctx, orc, n, P):
+    """n <= 128 (test_interpolate.R:5-9 runs N = 100, P = 10): the interpolation table is built by ONE launch per 64 entries, one
+    workgroup per length-scale (k_rbf_cov_chol_small: build, factor, tangent L Phi(L^-1 Sdot L^-T)), written straight into the
+    table: every entry against the oracle's rbf_cov_chol, and a single call (one workgroup up to n = 64, the launch chain beyond)
+    against the same."""
+    x = np.linspace(0.0, 0.5 * n, n)       # about one point per length-scale: well conditioned with the 1e-10 jitter
+    lp = np.linspace(0.3, 0.55, P)
+    ctx.interp_build(x, lp)
+    z = np.random.default_rng(n).standard_normal(n)
+    for p in (0, P // 2, P - 1):
+        L, dL = orc.rbf_cov_chol(x, lp[p])
+        f = ctx.approx_Lz(lp[p], z)            # at a knot the blend is the tabulated factor itself
+        assert np.max(np.abs(f - L @ z)) <= 1e-9 * max(1.0, np.max(np.abs(L @ z)))
+        Lg, dLg = ctx.rbf_cov_chol(x, lp[p])
+        np.testing.assert_allclose(Lg, L, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(dLg, dL, rtol=0, atol=1e-9 * max(1.0, np.abs(dL).max()))
+        assert np.all(np.triu(Lg, 1) == 0) and np.all(np.triu(dLg, 1) == 0)
+    if P >= 10:   # dv/dl at a knot is the tabulated tangent
+        _, dfdl = ctx.approx_Lz_grad(lp[1], z)
+        _, dL = orc.rbf_cov_chol(x, lp[1])
+        assert np.max(np.abs(dfdl - dL @ z)) <= 1e-7 * max(1.0, np.max(np.abs(dL @ z)))
+    ctx.interp_free()
