@@ -1892,6 +1892,31 @@ __device__ __forceinline__ void small_potrf_partial(double (&smem)[2][2][GK][GP]
         const int T = (mt + GT - 1) / GT, TN = (nt + GT - 1) / GT;
         for (int ti = 0; ti < T; ++ti) {
             const int vr = (mt - ti * GT < GT) ? mt - ti * GT : GT;  // valid rows of this tile row
+            if (vr == 1) {
+                // ONE row below the square part (the augmented row y^T when the order is a multiple of 128): its update is
+                // nt dot products of length nb -- thread = column, the row's panel entries from LDS, eight loads in flight --
+                // instead of a 64 x 64 MFMA quadrant per 64 columns (8 k cycles each for one useful row)
+                const int tid = fresh_tid(), row = ti * GT;
+                __syncthreads();
+                if (tid < nb) s_aux[tid] = X[(size_t)row + (size_t)tid * ld];
+                __syncthreads();
+                for (int j = tid; j < nt && j <= row; j += 256) {
+                    double a0 = 0.0, a1 = 0.0;
+                    for (int k0 = 0; k0 < nb; k0 += 8) {
+                        double u[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) u[q] = X[(size_t)j + (size_t)(k0 + q < nb ? k0 + q : nb - 1) * ld];
+#pragma unroll
+                        for (int q = 0; q < 8; q += 2) {
+                            a0 = fma(u[q], (k0 + q < nb) ? s_aux[k0 + q] : 0.0, a0);
+                            a1 = fma(u[q + 1], (k0 + q + 1 < nb) ? s_aux[k0 + q + 1] : 0.0, a1);
+                        }
+                    }
+                    C[(size_t)row + (size_t)j * ld] -= a0 + a1;
+                }
+                __syncthreads();
+                continue;
+            }
             for (int tj = 0; tj <= ti && tj < TN; ++tj) {
                 if (vr <= 64 && nb % GK == 0) {  // thin tile row (e.g. the augmented row alone): 64-row quadrants
                     for (int qn = 0; qn < 2; ++qn) {
