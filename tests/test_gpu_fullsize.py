@@ -254,3 +254,23 @@ def test_past_2_pow_31_elements_block_diagonal_decomposition(ctx):
              + ctx.joint_logml(t[h:], np.concatenate([ys[h:], yd[h:]]), 1.0, 0.5, 0.1, 1e-6)[0])
     print("joint order 48002: logml %.9f vs sum of clusters %.9f, rel %.2e" % (full, parts, abs(full - parts) / abs(full)))
     assert np.isfinite(full) and abs(full - parts) <= 1e-9 * abs(full)
+
+
+def test_trsv_wavefront_more_block_rows_than_resident_workgroups(ctx):
+    """k_trsv_wave at n = 33792: 264 block-rows, more than the 256 workgroups the chip holds at once (one per CU at this
+    kernel's register count) -- block-rows are handed out by a device ticket in START order, so a running workgroup only
+    ever waits for workgroups that are already running whatever order the hardware dispatches them in.  Residual of
+    L t = b against the right-hand side (a 9 GB factor: generated as a rank-one lower triangle plus a dominant diagonal)."""
+    n = 33792
+    rng = np.random.default_rng(5)
+    u = 0.02 * rng.standard_normal(n)
+    L = np.outer(u, u)
+    L = np.tril(L)
+    L[np.arange(n), np.arange(n)] = 1.0 + rng.random(n)
+    L = np.asfortranarray(L)
+    b = rng.standard_normal(n)
+    t = ctx.trsv_lower(L, b)
+    r = L @ t - b
+    err = np.max(np.abs(r)) / np.max(np.abs(b))
+    print("trsv n=%d (264 block-rows): residual %.2e" % (n, err))
+    assert np.all(np.isfinite(t)) and err <= 1e-12
